@@ -1,0 +1,146 @@
+/*
+ * movenet_hip.h -- C ABI of the MI355X-native WaveNet decoder path.
+ *
+ * The reference (cosmicBboy/movenet) is pure Python/PyTorch and has NO native
+ * interface; the boundary a drop-in must honour is the Python API of
+ * movenet/wavenet.py (WaveNet.forward :158-191, WaveNet.generate :193-239,
+ * receptive_fields :125-134).  This header is the C-ABI layer UNDER that API:
+ * every entry point below names the reference lines whose arithmetic it
+ * replaces.  movenet_amd/_native.py binds it with ctypes; INTEGRATION.md shows
+ * the stub a movenet maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (e.g. the PyTorch
+ *    caching allocator) unless the parameter is documented as a host array;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *    work is enqueued on it and nothing synchronises the host;
+ *  - functions return MVN_OK (0) or a negative MVN_ERR_* code and never throw;
+ *    mvn_last_error() returns a host string for the calling thread;
+ *  - one host thread per GPU; no internal threads; no hidden allocations (the
+ *    sizing helpers (mvn_*_floats) size the caller-provided workspaces).
+ *  - tensors are fp32, layouts are the reference's: audio (B, Q, T) one-hot is
+ *    represented by its class indices (B, T) int32; weights arrive in the
+ *    reference's state_dict layouts.
+ */
+#ifndef MOVENET_HIP_H
+#define MOVENET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVN_ABI_VERSION 1
+
+#define MVN_OK 0
+#define MVN_ERR_BAD_DIMS (-1)      /* unsupported / inconsistent dimensions   */
+#define MVN_ERR_BAD_ARG (-2)       /* NULL pointer, negative size, bad range  */
+#define MVN_ERR_TOO_SHORT (-3)     /* T < receptive_fields (ValueError in the
+                                      reference, movenet/wavenet.py:141-146)  */
+#define MVN_ERR_LAUNCH (-4)        /* HIP launch/runtime error                */
+#define MVN_ERR_UNSUPPORTED (-5)   /* variant not available for these dims    */
+
+/* movenet/wavenet.py:75-91 constructor arguments (context_in_channels is used
+ * by the video encoder only and is not part of the decoder kernels). */
+typedef struct mvn_dims {
+  int32_t layer_size;        /* dilations 2^0 .. 2^(layer_size-1) per stack  */
+  int32_t stack_size;
+  int32_t input_channels;    /* Q: mu-law classes                            */
+  int32_t residual_channels; /* C                                            */
+  int32_t skip_channels;     /* K                                            */
+} mvn_dims;
+
+/* Device pointers to the decoder parameters in the reference's own layouts
+ * (movenet/modules.py:19-26, :36-43, :52-65, :136-137).  Per-layer members are
+ * HOST arrays of n_layers device pointers.  ctx_* may be NULL (audio-only). */
+typedef struct mvn_params {
+  const float *causal_w;              /* causal_conv.conv.weight (C,Q,2)     */
+  const float *const *filter_w;       /* conv_filter.conv.weight (C,C,2)     */
+  const float *const *gate_w;         /* conv_gate.conv.weight   (C,C,2)     */
+  const float *const *residual_w;     /* conv_residual.weight    (C,C,1)     */
+  const float *const *residual_b;     /* conv_residual.bias      (C)         */
+  const float *const *skip_w;         /* conv_skip.weight        (K,C,1)     */
+  const float *const *skip_b;         /* conv_skip.bias          (K)         */
+  const float *const *ctx_filter_w;   /* context_conv_filter.weight (C,C,1)  */
+  const float *const *ctx_filter_b;
+  const float *const *ctx_gate_w;     /* context_conv_gate.weight (C,C,1)    */
+  const float *const *ctx_gate_b;
+  const float *head1_w;               /* dense_conv.conv1.weight (Q,K,1)     */
+  const float *head1_b;               /* dense_conv.conv1.bias   (Q)         */
+  const float *head2_w;               /* dense_conv.conv2.weight (Q,Q,1)     */
+  const float *head2_b;               /* dense_conv.conv2.bias   (Q)         */
+} mvn_params;
+
+int mvn_abi_version(void);
+const char *mvn_last_error(void);
+
+/* movenet/wavenet.py:125-134 (receptive_fields) and :136-147
+ * (compute_output_size; returns MVN_ERR_TOO_SHORT where the reference raises
+ * ValueError). */
+int mvn_receptive_fields(const mvn_dims *dims);
+int mvn_output_size(const mvn_dims *dims, int t_len);
+
+/* ------------------------------------------------------------------------
+ * Autoregressive generation (replaces the loop of movenet/wavenet.py:217-237:
+ * window forward -> [probs/T] -> softmax -> multinomial|argmax -> one-hot
+ * scatter) by a ring-buffer ("fast WaveNet") formulation that is
+ * result-equivalent: each layer keeps the last `dilation`
+ * inputs it saw, one generated sample costs one pass over the weights.
+ * ------------------------------------------------------------------------ */
+
+/* Kernel variants: GENERIC handles any dims (C,K <= 256, Q <= 1024, multiples
+ * of 4); the STREAM variants are the tuned ones (one workgroup per sequence,
+ * weights streamed from L2 through double-buffered registers).               */
+#define MVN_GEN_AUTO 0
+#define MVN_GEN_GENERIC 1
+#define MVN_GEN_STREAM 2
+
+/* Resolve MVN_GEN_AUTO for `dims`; returns the variant or a negative error. */
+int mvn_gen_variant(const mvn_dims *dims, int requested);
+
+/* Size in floats of the packed weight blob / of the ring-buffer state. */
+size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant);
+size_t mvn_gen_state_floats(const mvn_dims *dims, int batch);
+
+/* state_dict layouts -> the variant's streaming layout (done once per weight
+ * update; DESIGN.md "Data layout in HBM"). */
+int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *params,
+                         float *packed, void *stream);
+
+/* Advance every sequence over the time steps t in [t_begin, t_end).
+ *
+ *  samples      (batch, sample_stride) int32 class indices.  Step t consumes
+ *               samples[b][t] and predicts time t+1; when t+1 >= n_given and
+ *               t+1 < n_total the chosen class is written to samples[b][t+1].
+ *               Columns < n_given are never written (prompt / teacher forcing).
+ *  state        mvn_gen_state_floats() floats; must be zero before t = 0 and is
+ *               carried between calls (calls must cover t contiguously from 0).
+ *  temperature  > 0: sample from softmax(softmax(logits)/T) (the reference's
+ *               double softmax, movenet/wavenet.py:227-231); <= 0: first argmax
+ *               of softmax(softmax(logits)) (:233).
+ *  seed         Philox4x32-10 key; the draw for (b, t) does not depend on the
+ *               launch partition.
+ *  logits_out   optional (batch, n_total - logits_t0, Q): raw head output
+ *               predicting time u is stored at [b][u - logits_t0] for u >= logits_t0.
+ *  choices_out  optional (batch, n_total) int32: the class the model picks for
+ *               time u, also where samples[] is teacher-forced (u >= logits_t0).
+ */
+int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *state,
+                 int32_t *samples, int batch, int sample_stride, int n_total, int n_given,
+                 int t_begin, int t_end, float temperature, uint64_t seed,
+                 float *logits_out, int32_t *choices_out, int logits_t0, void *stream);
+
+/* (B,Q,T) one-hot fp32 <-> (B,T) int32 indices: movenet/dataset.py:285-288 and
+ * the scatter at movenet/wavenet.py:235-237.  onehot_to_index writes -1 where a
+ * column is not exactly one-hot (the host wrapper then refuses the input). */
+int mvn_onehot_to_index(const float *onehot, int32_t *index, int batch, int classes, int t_len,
+                        void *stream);
+int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, int batch,
+                        int classes, int t_len, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOVENET_HIP_H */

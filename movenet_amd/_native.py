@@ -1,0 +1,128 @@
+"""ctypes binding of libmovenet_hip.so (the C ABI in include/movenet_hip.h).
+
+There is deliberately NO fallback: if the library is missing or fails to load,
+every entry point raises ``NativeLibraryError`` -- the product never routes
+through PyTorch ops or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmovenet_hip.so")
+
+MVN_OK = 0
+MVN_ERR_BAD_DIMS = -1
+MVN_ERR_BAD_ARG = -2
+MVN_ERR_TOO_SHORT = -3
+MVN_ERR_LAUNCH = -4
+MVN_ERR_UNSUPPORTED = -5
+
+GEN_AUTO, GEN_GENERIC, GEN_STREAM = 0, 1, 2
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [
+        ("layer_size", C.c_int32),
+        ("stack_size", C.c_int32),
+        ("input_channels", C.c_int32),
+        ("residual_channels", C.c_int32),
+        ("skip_channels", C.c_int32),
+    ]
+
+
+_PP = C.POINTER(C.c_void_p)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("causal_w", C.c_void_p),
+        ("filter_w", _PP), ("gate_w", _PP),
+        ("residual_w", _PP), ("residual_b", _PP),
+        ("skip_w", _PP), ("skip_b", _PP),
+        ("ctx_filter_w", _PP), ("ctx_filter_b", _PP),
+        ("ctx_gate_w", _PP), ("ctx_gate_b", _PP),
+        ("head1_w", C.c_void_p), ("head1_b", C.c_void_p),
+        ("head2_w", C.c_void_p), ("head2_b", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); tests/test_capi.py checks the header against this
+SIGNATURES = {
+    "mvn_abi_version": (C.c_int, []),
+    "mvn_last_error": (C.c_char_p, []),
+    "mvn_receptive_fields": (C.c_int, [C.POINTER(Dims)]),
+    "mvn_output_size": (C.c_int, [C.POINTER(Dims), C.c_int]),
+    "mvn_gen_variant": (C.c_int, [C.POINTER(Dims), C.c_int]),
+    "mvn_gen_weights_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
+    "mvn_gen_state_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
+    "mvn_gen_pack_weights": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(Params), C.c_void_p,
+                                       C.c_void_p]),
+    "mvn_generate": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvn_onehot_to_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    "mvn_index_to_onehot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises NativeLibraryError loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m movenet_amd.csrc.build` "
+            "(or __graft_entry__.build()).  movenet_amd has no CPU/PyTorch fallback."
+        )
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.mvn_abi_version() != 1:
+        raise NativeLibraryError("libmovenet_hip.so ABI version mismatch")
+    _lib = handle
+    return handle
+
+
+def last_error() -> str:
+    return lib().mvn_last_error().decode(errors="replace")
+
+
+def check(rc: int, what: str) -> int:
+    """Map a negative status to the exception type the reference would raise."""
+    if rc >= 0:
+        return rc
+    msg = f"{what}: {last_error()} (status {rc})"
+    if rc == MVN_ERR_TOO_SHORT:
+        raise ValueError(last_error())  # movenet/wavenet.py:141-146
+    if rc in (MVN_ERR_BAD_DIMS, MVN_ERR_BAD_ARG, MVN_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def make_dims(layer_size: int, stack_size: int, input_channels: int, residual_channels: int,
+              skip_channels: int) -> Dims:
+    return Dims(layer_size, stack_size, input_channels, residual_channels, skip_channels)
+
+
+def ptr_array(ptrs: Sequence[int]):
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return arr, C.cast(arr, _PP)

@@ -1,0 +1,67 @@
+// Shared host/device helpers for the movenet HIP library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "movenet_hip.h"
+
+namespace mvn {
+
+constexpr int kWave = 64;
+constexpr float kLeakySlope = 0.01f;  // F.leaky_relu default (movenet/modules.py:140-141)
+
+// ---- host side ----------------------------------------------------------
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+
+inline int n_layers(const mvn_dims *d) { return d->layer_size * d->stack_size; }
+inline int dilation_of(const mvn_dims *d, int l) { return 1 << (l % d->layer_size); }
+inline long long dilation_sum(const mvn_dims *d) {
+  return (long long)d->stack_size * ((1LL << d->layer_size) - 1);
+}
+int validate_dims(const mvn_dims *d);
+
+// ---- device side --------------------------------------------------------
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }
+
+// tanh(f) * sigmoid(g), accurate libm forms (parity with the CPU path matters
+// more than the ~100 cycles they cost once per layer).
+__device__ __forceinline__ float gate(float f, float g) {
+  return tanhf(f) * (1.0f / (1.0f + expf(-g)));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox4x32-10, counter = (c0,c1,c2,c3), key = 64-bit seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1) {
+  uint32_t c[4] = {c0, c1, 0x6d766e31u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+}  // namespace mvn

@@ -1,0 +1,122 @@
+// Error plumbing, dimension checks and the one-hot <-> index converters.
+#include "common.h"
+
+#include <cstring>
+
+namespace mvn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char *what) {
+  if (e == hipSuccess) return MVN_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return MVN_ERR_LAUNCH;
+}
+
+int validate_dims(const mvn_dims *d) {
+  if (!d) {
+    set_error("dims is NULL");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (d->layer_size < 1 || d->layer_size > 20 || d->stack_size < 1 || d->stack_size > 64) {
+    set_error("layer_size %d / stack_size %d out of range", d->layer_size, d->stack_size);
+    return MVN_ERR_BAD_DIMS;
+  }
+  if (d->input_channels < 2 || d->residual_channels < 1 || d->skip_channels < 1) {
+    set_error("channel counts must be positive (Q=%d C=%d K=%d)", d->input_channels,
+              d->residual_channels, d->skip_channels);
+    return MVN_ERR_BAD_DIMS;
+  }
+  return MVN_OK;
+}
+
+// (B,Q,T) one-hot -> (B,T) index; -1 where the column is not exactly one-hot.
+__global__ void onehot_to_index_kernel(const float *__restrict__ x, int32_t *__restrict__ idx, int Q,
+                                       int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float *col = x + (size_t)b * Q * T + t;
+  int found = -1, bad = 0;
+  for (int q = 0; q < Q; ++q) {
+    const float v = col[(size_t)q * T];  // lanes walk t: coalesced
+    if (v == 1.0f) {
+      if (found >= 0) bad = 1;
+      found = q;
+    } else if (v != 0.0f) {
+      bad = 1;
+    }
+  }
+  idx[(size_t)b * T + t] = (bad || found < 0) ? -1 : found;
+}
+
+__global__ void index_to_onehot_kernel(const int32_t *__restrict__ idx, int stride,
+                                       float *__restrict__ x, int Q, int T) {
+  const int b = blockIdx.z;
+  const int q = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  x[((size_t)b * Q + q) * T + t] = (idx[(size_t)b * stride + t] == q) ? 1.0f : 0.0f;
+}
+
+}  // namespace mvn
+
+extern "C" {
+
+int mvn_abi_version(void) { return MVN_ABI_VERSION; }
+const char *mvn_last_error(void) { return mvn::g_err; }
+
+int mvn_receptive_fields(const mvn_dims *dims) {
+  int rc = mvn::validate_dims(dims);
+  if (rc) return rc;
+  return (int)(mvn::dilation_sum(dims) + dims->stack_size);
+}
+
+int mvn_output_size(const mvn_dims *dims, int t_len) {
+  int rf = mvn_receptive_fields(dims);
+  if (rf < 0) return rf;
+  int s = t_len - rf + 1;
+  if (s < 1) {
+    mvn::set_error(
+        "input time steps must be larger than the number of receptive fields. "
+        "Number of input timesteps = %d, receptive fields = %d",
+        t_len, rf);
+    return MVN_ERR_TOO_SHORT;
+  }
+  return s;
+}
+
+int mvn_onehot_to_index(const float *onehot, int32_t *index, int batch, int classes, int t_len,
+                        void *stream) {
+  if (!onehot || !index || batch < 0 || classes < 1 || t_len < 0) {
+    mvn::set_error("mvn_onehot_to_index: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0 || t_len == 0) return MVN_OK;
+  dim3 grid((t_len + 255) / 256, batch);
+  hipLaunchKernelGGL(mvn::onehot_to_index_kernel, grid, dim3(256), 0, (hipStream_t)stream, onehot,
+                     index, classes, t_len);
+  return mvn::check_hip(hipGetLastError(), "onehot_to_index");
+}
+
+int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, int batch,
+                        int classes, int t_len, void *stream) {
+  if (!onehot || !index || batch < 0 || classes < 1 || t_len < 0 || index_stride < t_len) {
+    mvn::set_error("mvn_index_to_onehot: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0 || t_len == 0) return MVN_OK;
+  dim3 grid((t_len + 255) / 256, classes, batch);
+  hipLaunchKernelGGL(mvn::index_to_onehot_kernel, grid, dim3(256), 0, (hipStream_t)stream, index,
+                     index_stride, onehot, classes, t_len);
+  return mvn::check_hip(hipGetLastError(), "index_to_onehot");
+}
+
+}  // extern "C"

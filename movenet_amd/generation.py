@@ -1,0 +1,163 @@
+"""Host side of the ring-buffer generator: owns the packed weights, the
+dilation-queue state and the sample buffer as torch tensors (device memory and
+stream plumbing only) and drives ``mvn_generate`` through the C ABI.
+
+Replaces the per-sample window loop of /root/reference/movenet/wavenet.py:217-237.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as N
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"movenet_amd: {what} must live on an MI355X device (got {t.device}); "
+            "there is no CPU path in this package"
+        )
+
+
+def pack_params(dims: N.Dims, sd: Dict[str, torch.Tensor], n_layers: int):
+    """Build the mvn_params struct from a state_dict of fp32 device tensors.
+    Returns (struct, keepalive) -- keepalive holds the pointer arrays and the
+    contiguous tensors the struct points into."""
+    keep = []
+
+    def dev(key: str) -> int:
+        t = sd[key]
+        _require_gpu(t, key)
+        if t.dtype != torch.float32:
+            raise TypeError(f"{key}: expected float32, got {t.dtype}")
+        t = t.detach().contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    def per_layer(name: str):
+        ptrs = [dev(f"residual_conv_stack.conv_layers.{l}.{name}") for l in range(n_layers)]
+        arr, cast = N.ptr_array(ptrs)
+        keep.append(arr)
+        return cast
+
+    p = N.Params()
+    p.causal_w = dev("causal_conv.conv.weight")
+    p.filter_w = per_layer("conv_filter.conv.weight")
+    p.gate_w = per_layer("conv_gate.conv.weight")
+    p.residual_w = per_layer("conv_residual.weight")
+    p.residual_b = per_layer("conv_residual.bias")
+    p.skip_w = per_layer("conv_skip.weight")
+    p.skip_b = per_layer("conv_skip.bias")
+    has_ctx = "residual_conv_stack.conv_layers.0.context_conv_filter.weight" in sd
+    if has_ctx:
+        p.ctx_filter_w = per_layer("context_conv_filter.weight")
+        p.ctx_filter_b = per_layer("context_conv_filter.bias")
+        p.ctx_gate_w = per_layer("context_conv_gate.weight")
+        p.ctx_gate_b = per_layer("context_conv_gate.bias")
+    p.head1_w = dev("dense_conv.conv1.weight")
+    p.head1_b = dev("dense_conv.conv1.bias")
+    p.head2_w = dev("dense_conv.conv2.weight")
+    p.head2_b = dev("dense_conv.conv2.bias")
+    return p, keep
+
+
+class RingGenerator:
+    """One batch of sequences being generated on one GPU.
+
+    >>> g = RingGenerator(cfg, state_dict, batch=16, n_total=19072, device="cuda:0")
+    >>> g.prime(prompt_idx)            # (B, RF) int class indices
+    >>> g.advance(16000)               # 16000 new samples per sequence
+    >>> g.samples                      # (B, n_total) int32
+    """
+
+    def __init__(self, layer_size: int, stack_size: int, input_channels: int,
+                 residual_channels: int, skip_channels: int, state_dict: Dict[str, torch.Tensor],
+                 batch: int, n_total: int, device, variant: int = N.GEN_AUTO,
+                 temperature: float = 0.0, seed: int = 0):
+        self.lib = N.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("movenet_amd.RingGenerator needs an MI355X device; no CPU path exists")
+        self.dims = N.make_dims(layer_size, stack_size, input_channels, residual_channels,
+                                skip_channels)
+        self.n_layers = layer_size * stack_size
+        self.Q = input_channels
+        self.rf = N.check(self.lib.mvn_receptive_fields(self.dims), "mvn_receptive_fields")
+        self.variant = N.check(self.lib.mvn_gen_variant(self.dims, variant), "mvn_gen_variant")
+        self.batch, self.n_total = int(batch), int(n_total)
+        self.temperature, self.seed = float(temperature), int(seed) & (2 ** 64 - 1)
+        with torch.cuda.device(self.device):
+            nw = self.lib.mvn_gen_weights_floats(self.dims, self.variant)
+            ns = self.lib.mvn_gen_state_floats(self.dims, self.batch)
+            self.packed = torch.empty(nw, dtype=torch.float32, device=self.device)
+            self.state = torch.zeros(max(ns, 1), dtype=torch.float32, device=self.device)
+            self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
+        self.t = 0          # number of time steps consumed so far
+        self.n_given = 1
+        self.repack(state_dict)
+
+    def repack(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        params, keep = pack_params(self.dims, state_dict, self.n_layers)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mvn_gen_pack_weights(self.dims, self.variant, params,
+                                                  self.packed.data_ptr(), _stream_ptr(self.device)),
+                    "mvn_gen_pack_weights")
+        # the source tensors must outlive the enqueued pack kernels
+        torch.cuda.current_stream(self.device).synchronize()
+        del keep
+
+    def reset(self) -> None:
+        self.state.zero_()
+        self.t = 0
+
+    def _run(self, t_begin: int, t_end: int, n_given: int, logits_out=None, choices_out=None,
+             logits_t0: int = 0) -> None:
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mvn_generate(
+                self.dims, self.variant, self.packed.data_ptr(), self.state.data_ptr(),
+                self.samples.data_ptr(), self.batch, self.samples.stride(0), self.n_total, n_given,
+                t_begin, t_end, self.temperature, self.seed,
+                None if logits_out is None else logits_out.data_ptr(),
+                None if choices_out is None else choices_out.data_ptr(),
+                logits_t0, _stream_ptr(self.device)), "mvn_generate")
+
+    def prime(self, prompt_idx: torch.Tensor) -> None:
+        """Load a (B, P) prompt (P >= 1 class indices per sequence) and run the
+        network over all but its last sample so that the queues are primed."""
+        _require_gpu(prompt_idx, "prompt indices")
+        B, P = prompt_idx.shape
+        if B != self.batch or P < 1 or P > self.n_total:
+            raise ValueError(f"prompt shape {tuple(prompt_idx.shape)} does not fit "
+                             f"(batch {self.batch}, n_total {self.n_total})")
+        self.reset()
+        self.samples.zero_()
+        self.samples[:, :P] = prompt_idx.to(torch.int32)
+        self.n_given = P
+        self._run(0, P - 1, P)
+        self.t = P - 1
+
+    def advance(self, n_new: int) -> None:
+        """Generate n_new further samples per sequence."""
+        t_end = min(self.t + n_new, self.n_total - 1)
+        self._run(self.t, t_end, self.n_given)
+        self.t = t_end
+
+    def teacher_forced(self, indices: torch.Tensor, logits_t0: int):
+        """Feed a fully given (B, n_total) history; return (choices, logits) for
+        times >= logits_t0 -- used by the parity tests."""
+        _require_gpu(indices, "indices")
+        assert indices.shape == (self.batch, self.n_total)
+        self.reset()
+        self.samples.copy_(indices.to(torch.int32))
+        logits = torch.zeros(self.batch, self.n_total - logits_t0, self.Q, dtype=torch.float32,
+                             device=self.device)
+        choices = torch.full((self.batch, self.n_total), -1, dtype=torch.int32, device=self.device)
+        self._run(0, self.n_total - 1, self.n_total, logits, choices, logits_t0)
+        self.t = self.n_total - 1
+        return choices, logits

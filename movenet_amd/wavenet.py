@@ -1,0 +1,192 @@
+"""MI355X-native WaveNet decoder behind the reference's model API.
+
+Drop-in for ``movenet.wavenet.WaveNet`` (/root/reference/movenet/wavenet.py:50-239):
+same constructor, same public attributes and module constants, same
+``forward`` / ``generate`` / ``receptive_fields`` / ``compute_output_size`` /
+``upsample_video`` signatures, same ``state_dict`` keys (so reference
+checkpoints load with ``load_state_dict``), same exception types.  The
+arithmetic runs in hand-written HIP kernels through the C ABI of
+``include/movenet_hip.h``; tensors must live on an MI355X -- there is no CPU
+or PyTorch-op fallback.
+
+The sub-modules below exist to hold parameters under the reference's names
+(and to draw the same default initialisation in the same order, so that the
+same ``torch.manual_seed`` yields the same initial weights as the reference);
+their own ``forward`` is never used.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native as N
+from .generation import RingGenerator, _require_gpu, _stream_ptr
+
+# module constants other movenet files import (movenet/wavenet.py:27-31)
+MAX_AUDIO_FRAMES = 160000
+MAX_VIDEO_FRAMES = 160
+VIDEO_KERNEL_SIZE = (1, 64, 64)
+UPSAMPLE_STRIDE = 10
+
+
+def upsample_kernel_size_solver(in_size, out_size, stride=1, padding=0, output_padding=0, dilation=1):
+    """Kernel size k with (in-1)*stride - 2*padding + dilation*(k-1) + output_padding + 1 == out
+    (the ConvTranspose1d length formula); same contract as movenet/wavenet.py:34-47."""
+    span = out_size - 1 - output_padding - (in_size - 1) * stride + 2 * padding
+    return (int(span / dilation + 1),)
+
+
+class _Named(nn.Module):
+    """Parameter holder: attribute name -> sub-module, nothing else."""
+
+    def __init__(self, **mods):
+        super().__init__()
+        for name, m in mods.items():
+            setattr(self, name, m)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder; the arithmetic lives in the HIP kernels")
+
+
+class _Stack(_Named):
+    def __init__(self, layer_size: int, stack_size: int, C: int, K: int):
+        nn.Module.__init__(self)
+        self.layer_size, self.stack_size = layer_size, stack_size
+        self.conv_layers = nn.ModuleList([
+            _Named(
+                conv_filter=_Named(conv=nn.Conv1d(C, C, 2, dilation=d, bias=False)),
+                conv_gate=_Named(conv=nn.Conv1d(C, C, 2, dilation=d, bias=False)),
+                context_conv_filter=nn.Conv1d(C, C, 1),
+                context_conv_gate=nn.Conv1d(C, C, 1),
+                conv_residual=nn.Conv1d(C, C, 1),
+                conv_skip=nn.Conv1d(C, K, 1),
+            )
+            for d in self.dilations
+        ])
+
+    @property
+    def dilations(self) -> List[int]:
+        return [1 << i for _ in range(self.stack_size) for i in range(self.layer_size)]
+
+
+class WaveNet(nn.Module):
+    def __init__(self, layer_size: int, stack_size: int, input_channels: int,
+                 residual_channels: int = 16, skip_channels: int = 16,
+                 context_in_channels: int = 1):
+        super().__init__()
+        self.layer_size = layer_size
+        self.stack_size = stack_size
+        self.input_channels = input_channels
+        self.residual_channels = residual_channels
+        self.skip_channels = skip_channels
+        C, K, Q = residual_channels, skip_channels, input_channels
+
+        # registration order == the reference's (wavenet.py:94-123): same RNG draws
+        self.video_conv = nn.Conv3d(context_in_channels, C, VIDEO_KERNEL_SIZE)
+        n_up = math.ceil(np.log10(MAX_AUDIO_FRAMES / MAX_VIDEO_FRAMES) + 1)
+        sizes = np.geomspace(MAX_VIDEO_FRAMES, MAX_AUDIO_FRAMES, num=n_up).astype(int)
+        self.video_transpose = nn.Sequential(*[
+            nn.ConvTranspose1d(C, C, upsample_kernel_size_solver(a, b, stride=UPSAMPLE_STRIDE),
+                               stride=UPSAMPLE_STRIDE)
+            for a, b in zip(sizes[:-1], sizes[1:])
+        ])
+        self.causal_conv = _Named(conv=nn.Conv1d(Q, C, 2, padding=1, bias=False))
+        self.residual_conv_stack = _Stack(layer_size, stack_size, C, K)
+        self.dense_conv = _Named(conv1=nn.Conv1d(K, Q, 1), conv2=nn.Conv1d(Q, Q, 1))
+
+        self._dims = N.make_dims(layer_size, stack_size, Q, C, K)
+        self._gen_variant = N.GEN_AUTO
+
+    # ---- shape arithmetic (host only) ---------------------------------
+    @property
+    def receptive_fields(self) -> int:
+        # sum of dilations + one more time point per stack (wavenet.py:125-134)
+        return sum(self.residual_conv_stack.dilations) + self.stack_size
+
+    def compute_output_size(self, x) -> int:
+        out = int(x.size(2)) - self.receptive_fields + 1
+        if out < 1:
+            raise ValueError(
+                "input time steps must be larger than the number of receptive "
+                f"fields. Number of input timesteps = {x.size(2)}, "
+                f"receptive fields = {self.receptive_fields}"
+            )
+        return out
+
+    # ---- helpers --------------------------------------------------------
+    def _indices_of(self, audio: torch.Tensor) -> torch.Tensor:
+        """(B,Q,T) one-hot -> (B,T) int32 on device (mvn_onehot_to_index)."""
+        _require_gpu(audio, "audio")
+        if audio.dim() != 3 or audio.size(1) != self.input_channels:
+            raise ValueError(f"audio must be (batch, {self.input_channels}, frames), "
+                             f"got {tuple(audio.shape)}")
+        x = audio.detach().to(torch.float32).contiguous()
+        B, Q, T = x.shape
+        idx = torch.empty(B, T, dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().mvn_onehot_to_index(x.data_ptr(), idx.data_ptr(), B, Q, T,
+                                                _stream_ptr(x.device)), "mvn_onehot_to_index")
+        if B * T and int(idx.min().item()) < 0:
+            raise ValueError(
+                "movenet_amd.WaveNet expects one-hot audio (movenet/dataset.py:278-289); "
+                "a column of the input is not one-hot")
+        return idx
+
+    def _one_hot_of(self, idx: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        B, T = idx.shape
+        out = torch.empty(B, self.input_channels, T, dtype=torch.float32, device=idx.device)
+        with torch.cuda.device(idx.device):
+            N.check(N.lib().mvn_index_to_onehot(idx.data_ptr(), idx.stride(0), out.data_ptr(), B,
+                                                self.input_channels, T, _stream_ptr(idx.device)),
+                    "mvn_index_to_onehot")
+        return out if dtype == torch.float32 else out.to(dtype)
+
+    def _decoder_state(self):
+        return {k: v for k, v in self.state_dict().items() if not k.startswith("video_")}
+
+    # ---- model API ------------------------------------------------------
+    def upsample_video(self, video):
+        raise NotImplementedError(
+            "video conditioning (SURVEY.md section 8f, row F1) is not built yet")
+
+    def forward(self, audio, video=None, global_features=None, output_unnormalized: bool = True,
+                remove_last: bool = True):
+        from .ops import wavenet_forward  # HIP full-sequence kernels
+        if video is not None:
+            raise NotImplementedError(
+                "the video-conditioned forward raises in the reference itself "
+                "(SURVEY.md Q6); conditioning is a later row (section 8f F1)")
+        return wavenet_forward(self, audio, output_unnormalized=output_unnormalized,
+                               remove_last=remove_last)
+
+    @torch.no_grad()
+    def generate(self, audio, video=None, global_features=None, n_samples: Optional[int] = None,
+                 temperature: float = 1.0):
+        """wavenet.py:193-239: copy the first RF prompt samples, then generate
+        autoregressively up to n_samples (default: the prompt's own length)."""
+        self.eval()  # the reference leaves the module in eval mode
+        if video is not None:
+            raise NotImplementedError(
+                "conditioned generation raises in the reference itself (SURVEY.md Q7)")
+        rf = self.receptive_fields
+        n_total = int(audio.shape[2]) if n_samples is None else int(n_samples)
+        idx = self._indices_of(audio)
+        if idx.shape[1] < rf or n_total <= rf:
+            # nothing to generate: the reference returns zeros with the prompt copied in
+            out = torch.zeros(audio.shape[0], audio.shape[1], n_total, dtype=audio.dtype,
+                              device=audio.device)
+            n = min(rf, n_total, audio.shape[2])
+            out[:, :, :n] = audio[:, :, :n]
+            return out
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
+                            self.residual_channels, self.skip_channels, self._decoder_state(),
+                            batch=idx.shape[0], n_total=n_total, device=audio.device,
+                            variant=self._gen_variant, temperature=float(temperature), seed=seed)
+        gen.prime(idx[:, :rf])
+        gen.advance(n_total - rf)
+        return self._one_hot_of(gen.samples, audio.dtype)
