@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: autoregressive audio samples/sec on BASELINE config 2.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "Config 2"): 30-layer
+(10 x 3 dilation cycles) WaveNet, Q=256 mu-law classes, C=K=64, batch 16
+sequences per GPU, fp32, synthetic random prompt of RF=3072 samples, seeded
+random-init weights.  One STEP = one pass of the hot path over the batch:
+16000 new samples (1 s of 16 kHz audio) for each of the 16 sequences, greedy
+(temperature 0; the mode the reference's own test uses).  Queue priming over
+the prompt happens before the timed region and is reported separately.
+Multi-GPU = independent clips per rank (weak scaling), no data-path collective.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+BATCH = 16
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def flop_per_sample(cfg) -> int:
+    """MACs = L(5C^2 + CK) + KQ + Q^2 per generated sample
+    per sequence (the causal conv on a one-hot input is a gather)."""
+    L = cfg["layer_size"] * cfg["stack_size"]
+    C, K, Q = cfg["residual_channels"], cfg["skip_channels"], cfg["input_channels"]
+    return 2 * (L * (5 * C * C + C * K) + K * Q + Q * Q)
+
+
+def log(msg: str) -> None:
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """Threads for the CPU baseline: the process's CPU share (affinity mask,
+    capped by the cgroup CPU quota), overridable with MOVENET_CPU_THREADS."""
+    if os.environ.get("MOVENET_CPU_THREADS"):
+        return max(1, int(os.environ["MOVENET_CPU_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 64)
+
+
+def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
+    """The reference's NAIVE windowed generate (wavenet.py:217-237) on the host
+    cores, via the CPU oracle (kind "port": pinned bit-exact to the reference in
+    the build container by tests/golden/make_golden.py).  Per-step cost is
+    constant (the window is always RF long), so a bounded sample suffices."""
+    from oracle import wavenet_oracle as O
+    from movenet_amd.utils.weights import one_hot, synthetic_indices
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
+    dims = O.Dims(**CFG)
+    rf = dims.receptive_fields
+    prompt = one_hot(synthetic_indices(BATCH, rf, CFG["input_channels"], 1234), CFG["input_channels"])
+    t0 = None
+    with torch.no_grad():
+        # generate_windowed runs exactly the reference loop; time n_timed steady steps
+        gen = torch.zeros(BATCH, CFG["input_channels"], rf + n_warm + n_timed)
+        gen[:, :, :rf] = prompt
+        for i in range(rf, rf + n_warm + n_timed):
+            if i == rf + n_warm:
+                t0 = time.perf_counter()
+            log(f"cpu_baseline: window forward {i - rf + 1}/{n_warm + n_timed}")
+            out = O.forward(sd, dims, gen[:, :, i - rf:i], output_unnormalized=True, remove_last=False)
+            choice = O.pre_sampling_probs(out, 0.0).argmax(1, keepdim=True)
+            gen[:, :, [i]] = torch.zeros_like(out).scatter_(1, choice, 1)
+        dt = time.perf_counter() - t0
+    return {
+        "value": BATCH * n_timed / dt,
+        "unit": "samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_timed} steady-state steps of the reference's naive windowed generate "
+                  f"(RF={rf} window forward per sample) at batch {BATCH} after {n_warm} warm-ups, "
+                  f"torch CPU fp32, {dt:.2f} s",
+        "samples_per_s_per_sequence": n_timed / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--new-samples", type=int, default=16000, help="samples per sequence per step")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from movenet_amd.generation import RingGenerator
+    from movenet_amd.utils.weights import make_state_dict, synthetic_indices
+
+    sd_cpu = make_state_dict(**CFG, seed=0)
+    sd = {k: v.to(dev) for k, v in sd_cpu.items() if not k.startswith("video_")}
+    rf = 3072
+    n_new, K, W = args.new_samples, args.steps, args.warmup
+    n_total = rf + (K + W) * n_new + 1
+    gen = RingGenerator(**CFG, state_dict=sd, batch=BATCH, n_total=n_total, device=dev,
+                        variant=args.variant, temperature=0.0, seed=0)
+    prompt = synthetic_indices(BATCH, rf, CFG["input_channels"], 1234 + rank).to(dev)
+
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    gen.prime(prompt)
+    torch.cuda.synchronize(dev)
+    prime_ms = (time.perf_counter() - t0) * 1e3
+    log(f"rank {rank}: primed {rf} samples in {prime_ms:.1f} ms")
+
+    for _ in range(W):
+        gen.advance(n_new)
+        torch.cuda.synchronize(dev)
+        log(f"rank {rank}: warm-up step done")
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()   # torch's current stream == the stream mvn_generate is launched on
+        gen.advance(n_new)
+        ev[k][1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    log(f"rank {rank}: {K} timed steps in {elapsed:.3f} s; launch ms {kernel_ms}")
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    assert gen.t == rf - 1 + (K + W) * n_new
+    total_samples = world * BATCH * n_new * K
+    value = total_samples / elapsed
+    avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    flops_per_launch = flop_per_sample(CFG) * BATCH * n_new
+    achieved = flops_per_launch / avg_kernel_s / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "autoregressive audio samples/sec (16 kHz, 30-layer WaveNet, whole job)",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: 30-layer (10x3) WaveNet, Q=256, C=K=64, 16 kHz, "
+                            "batch 16 sequences per GPU, greedy autoregressive generate",
+                "batch_per_gpu": BATCH,
+                "new_samples_per_sequence_per_step": n_new,
+                "prompt": rf,
+                "kernel_variant": {1: "generic", 2: "stream64"}[gen.variant],
+                "parallelism": f"independent clips x{world} (no collective)",
+            },
+            "samples_per_s_per_gpu": value / world,
+            "samples_per_s_per_sequence": value / world / BATCH,
+            "us_per_sample_step": elapsed / K / n_new * 1e6,
+            "prime_ms": prime_ms,
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
+                "traffic": None,
+                "kernel": "gen_stream64_kernel" if gen.variant == 2 else "gen_generic_kernel",
+                "flop_per_launch": flops_per_launch,
+                "avg_launch_ms": avg_kernel_s * 1e3,
+                "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(sd_cpu)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,76 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
                  int t_begin, int t_end, float temperature, uint64_t seed,
                  float *logits_out, int32_t *choices_out, int logits_t0, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Full-sequence forward (replaces movenet/wavenet.py:166-191: causal conv ->
+ * L gated residual layers -> sum of skips -> dense head -> [drop last] ->
+ * [softmax]) and its backward.  Used for training, for forward() and to prime
+ * the generator's queues from a prompt.
+ *
+ * Activations live on an ABSOLUTE time axis: every per-layer tensor is
+ * (batch, channels, Tp) with Tp = mvn_padded_len(T) and column t = input time
+ * t; layer l's input is valid for t >= A_l (A_0 = 0, A_{l+1} = A_l + d_l), so
+ * the reference's right-aligned slices (modules.py:84, :91) become "same t".
+ * Skip/head tensors are (batch, channels, Sp), Sp = mvn_padded_len(S),
+ * S = T - RF + 1, column s = time RF-1+s.
+ * ------------------------------------------------------------------------ */
+int mvn_padded_len(int n); /* n rounded up to a multiple of 64 */
+
+/* Caller-provided device buffers (floats).  n_act = save ? L+1 : 2. */
+typedef struct mvn_fwd_buffers {
+  float *acts;  /* n_act x (B, C, Tp): layer inputs; acts[0] = causal conv out  */
+  float *th;    /* save: L x (B, C, Tp) tanh(f);      else NULL                 */
+  float *sg;    /* save: L x (B, C, Tp) sigmoid(g);   else NULL                 */
+  float *z;     /* (B, C, Tp) gated activation scratch                          */
+  float *skip;  /* (B, K, Sp) sum of skips                                      */
+  float *a1;    /* (B, Q, Sp) head hidden activation lrelu(conv1(lrelu(skip)))  */
+} mvn_fwd_buffers;
+
+/* out: (B, Q, S_out) contiguous, S_out = S - (remove_last ? 1 : 0); softmax over
+ * Q when `normalize` (the reference's inverted flag output_unnormalized=True,
+ * wavenet.py:189-191).  save != 0 keeps what mvn_backward needs in `buf`. */
+int mvn_forward(const mvn_dims *dims, const mvn_params *params, const int32_t *index,
+                int index_stride, int batch, int t_len, const mvn_fwd_buffers *buf, float *out,
+                int normalize, int remove_last, int save, void *stream);
+
+/* Gradients, same layouts as mvn_params (members may not be NULL except ctx_*);
+ * mvn_backward ACCUMULATES into them (zero them first for a fresh gradient). */
+typedef struct mvn_param_grads {
+  float *causal_w;
+  float *const *filter_w;
+  float *const *gate_w;
+  float *const *residual_w;
+  float *const *residual_b;
+  float *const *skip_w;
+  float *const *skip_b;
+  float *head1_w;
+  float *head1_b;
+  float *head2_w;
+  float *head2_b;
+} mvn_param_grads;
+
+/* Scratch for the backward pass (floats). */
+typedef struct mvn_bwd_buffers {
+  float *dx_a;   /* (B, C, Tp) */
+  float *dx_b;   /* (B, C, Tp) */
+  float *dfg;    /* (B, 2C, Tp) */
+  float *dskip;  /* (B, K, Sp) */
+  float *da1;    /* (B, Q, Sp) */
+  float *dlogit; /* (B, Q, Sp) */
+} mvn_bwd_buffers;
+
+/* dout: gradient w.r.t. mvn_forward's `out` (same shape); `out` itself is needed
+ * when normalize != 0 (softmax backward).  Requires the forward ran with save. */
+int mvn_backward(const mvn_dims *dims, const mvn_params *params, const mvn_param_grads *grads,
+                 const int32_t *index, int index_stride, int batch, int t_len,
+                 const mvn_fwd_buffers *fwd, const mvn_bwd_buffers *bwd, const float *out,
+                 const float *dout, int normalize, int remove_last, void *stream);
+
+/* Fill the generator's dilation queues from a saved forward (acts of a prompt
+ * of t_len >= RF samples): equivalent to mvn_generate over t in [0, t_len-1). */
+int mvn_gen_prime_from_forward(const mvn_dims *dims, const mvn_fwd_buffers *fwd, int batch,
+                               int t_len, float *state, void *stream);
+
 /* (B,Q,T) one-hot fp32 <-> (B,T) int32 indices: movenet/dataset.py:285-288 and
  * the scatter at movenet/wavenet.py:235-237.  onehot_to_index writes -1 where a
  * column is not exactly one-hot (the host wrapper then refuses the input). */

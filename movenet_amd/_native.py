@@ -52,6 +52,30 @@ class Params(C.Structure):
     ]
 
 
+_FP = C.POINTER(C.c_void_p)
+
+
+class FwdBuffers(C.Structure):
+    _fields_ = [("acts", C.c_void_p), ("th", C.c_void_p), ("sg", C.c_void_p), ("z", C.c_void_p),
+                ("skip", C.c_void_p), ("a1", C.c_void_p)]
+
+
+class ParamGrads(C.Structure):
+    _fields_ = [
+        ("causal_w", C.c_void_p),
+        ("filter_w", _PP), ("gate_w", _PP),
+        ("residual_w", _PP), ("residual_b", _PP),
+        ("skip_w", _PP), ("skip_b", _PP),
+        ("head1_w", C.c_void_p), ("head1_b", C.c_void_p),
+        ("head2_w", C.c_void_p), ("head2_b", C.c_void_p),
+    ]
+
+
+class BwdBuffers(C.Structure):
+    _fields_ = [("dx_a", C.c_void_p), ("dx_b", C.c_void_p), ("dfg", C.c_void_p),
+                ("dskip", C.c_void_p), ("da1", C.c_void_p), ("dlogit", C.c_void_p)]
+
+
 # name -> (restype, argtypes); tests/test_capi.py checks the header against this
 SIGNATURES = {
     "mvn_abi_version": (C.c_int, []),
@@ -66,6 +90,16 @@ SIGNATURES = {
     "mvn_generate": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvn_padded_len": (C.c_int, [C.c_int]),
+    "mvn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.c_void_p, C.c_int, C.c_int,
+                              C.c_int, C.POINTER(FwdBuffers), C.c_void_p, C.c_int, C.c_int,
+                              C.c_int, C.c_void_p]),
+    "mvn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(ParamGrads),
+                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FwdBuffers),
+                               C.POINTER(BwdBuffers), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                               C.c_void_p]),
+    "mvn_gen_prime_from_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(FwdBuffers), C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p]),
     "mvn_onehot_to_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
     "mvn_index_to_onehot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmovenet_hip.so")
 STAMP = os.path.join(LIB_DIR, "libmovenet_hip.stamp")
 
-SOURCES = ["common.hip", "generate.hip"]
+SOURCES = ["common.hip", "generate.hip", "sequence.hip"]
 HEADERS = ["common.h", os.path.join(ROOT, "include", "movenet_hip.h")]
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
@@ -63,7 +63,8 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -
     cmd += _source_paths() + ["-o", LIB_PATH]
     if verbose:
         print("[movenet_amd] " + " ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, cwd=LIB_DIR, capture_output=True, text=True)
+    cwd = os.path.join(LIB_DIR, "temps") if keep_temps else LIB_DIR
+    proc = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
     if proc.returncode != 0:
         sys.stderr.write(proc.stdout + proc.stderr)
         raise RuntimeError("hipcc failed building libmovenet_hip.so")

@@ -1,0 +1,732 @@
+// Full-sequence forward and backward of the WaveNet decoder on gfx950.
+//
+// Reference arithmetic: /root/reference/movenet/wavenet.py:166-191 (forward),
+// movenet/modules.py:28-30 (causal conv), :67-93 (gated residual layer),
+// :139-142 (dense head); the backward is the exact adjoint of those lines.
+//
+// Everything convolution-shaped here is a "weights x time" product
+//     Y[b][m][t] = sum_k W[m][k] * X[b][k][t (+shift_k)]
+// with tiny M,K (16..256 channels) and long t, so ONE MFMA kernel family
+// (gemm_wx_kernel<Op>) serves every forward conv and every data-gradient, and
+// ONE family (wgrad_kernel<Op>) serves every weight gradient (a product over
+// time, split across workgroups and combined with fp32 atomics).  The Op
+// functor supplies operand addressing (taps, transposes, f/g row pairing,
+// validity masks) and the fused epilogue (gating, residual add, skip
+// accumulation, leaky-ReLU and its derivative...).  Both use
+// v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain.
+//
+// Activations use an ABSOLUTE time axis (see movenet_hip.h): tensor (B, ch, Tp),
+// column t = input time t, layer l's input valid for t >= A_l.
+#include "common.h"
+
+namespace mvn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Act {  // (B, ch, ld) view
+  float *p;
+  long long sb;  // batch stride (floats)
+  int ld;        // row stride (floats)
+  __device__ __forceinline__ float *at(int b, int ch, int t) const {
+    return p + (size_t)b * sb + (size_t)ch * ld + t;
+  }
+};
+
+// accumulator register r of lane `lane` -> row inside a 32x32 MFMA tile
+__device__ __forceinline__ int acc_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// ======================================================================
+// gemm_wx: Y[m][t] = sum_k W(m,k) X(k,t), block tile 64(m) x 256(t),
+// 4 waves, wave w owns t in [64w, 64w+64) as 2x2 MFMA tiles.
+// ======================================================================
+constexpr int GX_KC = 16;  // k per LDS chunk
+
+template <class Op>
+__global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
+  __shared__ float Ws[2][GX_KC][64];
+  __shared__ float Xs[2][GX_KC][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, mb = blockIdx.y;
+  const int t0 = op.t_begin + blockIdx.x * 256;
+  const int nchunk = (op.K + GX_KC - 1) / GX_KC;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float wreg[4], xreg[16];
+  auto gload = [&](int c) {
+    const int k0 = c * GX_KC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + (tid & 63), k0 + (tid >> 6) + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xreg[j] = op.x(b, k0 + j, t0 + tid);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ws[buf][(tid >> 6) + 4 * j][tid & 63] = wreg[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Xs[buf][j][tid] = xreg[j];
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < GX_KC / 2; ++kk) {
+      const int kr = 2 * kk + (lane >> 5);
+      const float a0 = Ws[buf][kr][lane & 31], a1 = Ws[buf][kr][32 + (lane & 31)];
+      const float b0 = Xs[buf][kr][64 * wave + (lane & 31)];
+      const float b1 = Xs[buf][kr][64 * wave + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: acc[mi][ni][r] is row 32*mi + acc_row(r), column 64*wave + 32*ni + (lane&31)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int t = t0 + 64 * wave + 32 * ni + (lane & 31);
+    if (t < op.t_end) op.epilogue(b, mb, t, lane, acc[0][ni], acc[1][ni]);
+  }
+}
+
+// ---- forward ops -------------------------------------------------------
+// F1: f,g = dilated k=2 conv, z = tanh(f)*sigmoid(g).  Row block mb covers
+// channels [32mb, 32mb+32): tile rows 0..31 = filter rows, 32..63 = gate rows,
+// so a lane holds f and g of the same (channel, t) in matching registers.
+struct FgOp {
+  int K, t_begin, t_end, C, d;
+  const float *wf, *wg;  // (C, C, 2)
+  Act xin;               // layer input
+  Act z, th, sg;         // outputs (th/sg.p may be NULL)
+  __device__ __forceinline__ float w(int m, int k) const {
+    const int r = m & 63, c = (m >> 6) * 32 + (r & 31);
+    const int tap = k >= C, kc = k - tap * C;
+    if (c >= C || k >= 2 * C) return 0.f;
+    const float *src = r < 32 ? wf : wg;
+    return src[((size_t)c * C + kc) * 2 + tap];
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    if (k >= 2 * C || t >= t_end) return 0.f;
+    return k < C ? *xin.at(b, k, t - d) : *xin.at(b, k - C, t);  // t >= t_begin >= d
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &f,
+                                           const f32x16 &g) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = mb * 32 + acc_row(r, lane);
+      if (c < C) {
+        const float tv = tanhf(f[r]), sv = 1.0f / (1.0f + expf(-g[r]));
+        *z.at(b, c, t) = tv * sv;
+        if (th.p) {
+          *th.at(b, c, t) = tv;
+          *sg.at(b, c, t) = sv;
+        }
+      }
+    }
+  }
+};
+
+// F2: residual 1x1 (+bias +input) and skip 1x1 (+bias, accumulated for t >= t_skip0).
+// Rows: [0,C) residual channels, [C, C+Kc) skip channels.
+struct RsOp {
+  int K, t_begin, t_end, C, Kc, t_skip0;
+  const float *wr, *br, *ws, *bs;  // (C,C,1),(C),(Kc,C,1),(Kc)
+  Act z, xin, xout, skip;
+  int first_layer;  // skip is overwritten instead of accumulated
+  __device__ __forceinline__ float w(int m, int k) const {
+    if (k >= C) return 0.f;
+    if (m < C) return wr[(size_t)m * C + k];
+    if (m < C + Kc) return ws[(size_t)(m - C) * C + k];
+    return 0.f;
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    return (k < C && t < t_end) ? *z.at(b, k, t) : 0.f;
+  }
+  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
+    if (m < C) {
+      if (xout.p) *xout.at(b, m, t) = (v + br[m]) + *xin.at(b, m, t);
+    } else if (m < C + Kc && t >= t_skip0) {
+      float *s = skip.at(b, m - C, t - t_skip0);
+      const float add = v + bs[m - C];
+      *s = first_layer ? add : *s + add;
+    }
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
+                                           const f32x16 &a1) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
+      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+    }
+  }
+};
+
+// F3/F4 and the head's data-gradients: plain 1x1 with selectable input/output maps.
+enum { IN_ID = 0, IN_LRELU = 1 };
+enum { OUT_BIAS = 0, OUT_BIAS_LRELU = 1, OUT_MUL_DLRELU = 2 };
+template <int IN, int OUT, bool TRANSPOSED>
+struct DenseOp {
+  int K, t_begin, t_end, M;
+  const float *wmat;  // (rows, cols, 1): W[m][k] = TRANSPOSED ? wmat[k*M_src + m] : wmat[m*K + k]
+  int ldw;            // row length of wmat
+  const float *bias;
+  Act xin, yout, ref;  // ref: activation whose sign gates the lrelu derivative
+  int t_out_end;       // columns >= this are not stored (remove_last)
+  __device__ __forceinline__ float w(int m, int k) const {
+    if (m >= M || k >= K) return 0.f;
+    return TRANSPOSED ? wmat[(size_t)k * ldw + m] : wmat[(size_t)m * ldw + k];
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    if (k >= K || t >= t_end) return 0.f;
+    const float v = *xin.at(b, k, t);
+    return IN == IN_LRELU ? leaky(v) : v;
+  }
+  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
+    if (m >= M || t >= t_out_end) return;
+    if (OUT == OUT_BIAS) v = v + bias[m];
+    if (OUT == OUT_BIAS_LRELU) v = leaky(v + bias[m]);
+    if (OUT == OUT_MUL_DLRELU) v = v * (*ref.at(b, m, t) > 0.f ? 1.0f : kLeakySlope);
+    *yout.at(b, m, t) = v;
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
+                                           const f32x16 &a1) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
+      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+    }
+  }
+};
+
+// ---- backward data-gradient ops ------------------------------------------
+// B3: dz = Wr^T dxo + Ws^T dskip ; df = dz*sg*(1-th^2) ; dg = dz*th*sg*(1-sg)
+struct DzOp {
+  int K, t_begin, t_end, C, Kc, t_skip0;
+  const float *wr, *ws;
+  Act dxo, dskip, th, sg, dfg;  // dxo.p == NULL for the last layer (output unused)
+  __device__ __forceinline__ float w(int m, int k) const {
+    if (m >= C) return 0.f;
+    if (k < C) return dxo.p ? wr[(size_t)k * C + m] : 0.f;
+    if (k < C + Kc) return ws[(size_t)(k - C) * C + m];
+    return 0.f;
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    if (t >= t_end) return 0.f;
+    if (k < C) return dxo.p ? *dxo.at(b, k, t) : 0.f;
+    if (k < C + Kc) return t >= t_skip0 ? *dskip.at(b, k - C, t - t_skip0) : 0.f;
+    return 0.f;
+  }
+  __device__ __forceinline__ void one(int b, int m, int t, float dz) const {
+    if (m >= C) return;
+    const float tv = *th.at(b, m, t), sv = *sg.at(b, m, t);
+    *dfg.at(b, m, t) = dz * sv * (1.0f - tv * tv);
+    *dfg.at(b, C + m, t) = dz * tv * sv * (1.0f - sv);
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
+                                           const f32x16 &a1) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
+      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+    }
+  }
+};
+
+// B4: dx[u] = [u>=t_lo] (dxo[u] + W1^T dfg[u]) + [u+d<T] W0^T dfg[u+d]
+//     k in [0,2C): tap 1 rows of dfg at u ; k in [2C,4C): tap 0 rows at u+d
+struct DxOp {
+  int K, t_begin, t_end, C, d, t_lo;  // t_lo = A_{l+1}; outputs cover [A_l, T)
+  const float *wf, *wg;
+  Act dxo, dfg, dxi;
+  __device__ __forceinline__ float w(int m, int k) const {
+    if (m >= C || k >= 4 * C) return 0.f;
+    const int tap = k < 2 * C ? 1 : 0, kk = k - (tap ? 0 : 2 * C);
+    const float *src = kk < C ? wf : wg;
+    const int o = kk < C ? kk : kk - C;
+    return src[((size_t)o * C + m) * 2 + tap];
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    if (k >= 4 * C || t >= t_end) return 0.f;
+    if (k < 2 * C) return t >= t_lo ? *dfg.at(b, k, t) : 0.f;
+    return t + d < t_end ? *dfg.at(b, k - 2 * C, t + d) : 0.f;
+  }
+  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
+    if (m >= C) return;
+    if (dxo.p && t >= t_lo) v += *dxo.at(b, m, t);
+    *dxi.at(b, m, t) = v;
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
+                                           const f32x16 &a1) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
+      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+    }
+  }
+};
+
+// ======================================================================
+// wgrad: dW(m,n) += sum_{b,t} A(b,m,t) * X(b,n,t); block tile 64 x 64, each
+// wave one 32x32 MFMA tile, K = time.  Grid: (time chunks * B, M/64 * N/64).
+// ======================================================================
+constexpr int WG_T = 64;       // time per LDS tile
+constexpr int WG_CHUNK = 2048;  // time per block
+
+template <class Op>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int chunks_per_b) {
+  __shared__ float As[64][WG_T + 1];
+  __shared__ float Xs[64][WG_T + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
+  const int mi = wave >> 1, ni = wave & 1;
+  const int tb = op.t_begin + ch * WG_CHUNK, te = min(op.t_end, tb + WG_CHUNK);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+
+  for (int t0 = tb; t0 < te; t0 += WG_T) {
+    // 64 rows x 64 t per operand: wave w loads rows w, w+4, ...
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int row = wave + 4 * j, t = t0 + lane;
+      const bool ok = t < te;
+      As[row][lane] = ok ? op.a(b, mblk * 64 + row, t) : 0.f;
+      Xs[row][lane] = ok ? op.x(b, nblk * 64 + row, t) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < WG_T / 2; ++kk) {
+      const int tc = 2 * kk + (lane >> 5);
+      const float av = As[32 * mi + (lane & 31)][tc];
+      const float xv = Xs[32 * ni + (lane & 31)][tc];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
+    }
+    if (nblk == 0 && tid < 64) {
+#pragma unroll 8
+      for (int t = 0; t < WG_T; ++t) bsum += As[tid][t];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mblk * 64 + 32 * mi + acc_row(r, lane), n = nblk * 64 + 32 * ni + (lane & 31);
+    float *dst = op.dw(m, n);
+    if (dst) atomicAdd(dst, acc[r]);
+  }
+  if (nblk == 0 && tid < 64) {
+    float *dst = op.db(mblk * 64 + tid);
+    if (dst) atomicAdd(dst, bsum);
+  }
+}
+
+// dWf/dWg: A = dfg rows (f | g), X = layer input (past | cur) -> (C,C,2) taps
+struct WgFgOp {
+  int t_begin, t_end, C, d;
+  Act dfg, xin;
+  float *dwf, *dwg;
+  __device__ __forceinline__ float a(int b, int m, int t) const {
+    return m < 2 * C ? *dfg.at(b, m, t) : 0.f;
+  }
+  __device__ __forceinline__ float x(int b, int n, int t) const {
+    if (n >= 2 * C) return 0.f;
+    return n < C ? *xin.at(b, n, t - d) : *xin.at(b, n - C, t);
+  }
+  __device__ __forceinline__ float *dw(int m, int n) const {
+    if (m >= 2 * C || n >= 2 * C) return nullptr;
+    float *base = m < C ? dwf : dwg;
+    const int o = m < C ? m : m - C, tap = n >= C, c = n - tap * C;
+    return base + ((size_t)o * C + c) * 2 + tap;
+  }
+  __device__ __forceinline__ float *db(int m) const { return nullptr; }
+};
+
+// dWr,dbr,dWs,dbs: A = [dxo ; dskip], X = z = th*sg
+struct WgRsOp {
+  int t_begin, t_end, C, Kc, t_skip0;
+  Act dxo, dskip, th, sg;  // dxo.p == NULL for the last layer
+  float *dwr, *dbr, *dws, *dbs;
+  __device__ __forceinline__ float a(int b, int m, int t) const {
+    if (m < C) return dxo.p ? *dxo.at(b, m, t) : 0.f;
+    if (m < C + Kc) return t >= t_skip0 ? *dskip.at(b, m - C, t - t_skip0) : 0.f;
+    return 0.f;
+  }
+  __device__ __forceinline__ float x(int b, int n, int t) const {
+    return n < C ? *th.at(b, n, t) * *sg.at(b, n, t) : 0.f;
+  }
+  __device__ __forceinline__ float *dw(int m, int n) const {
+    if (n >= C) return nullptr;
+    if (m < C) return dxo.p ? dwr + (size_t)m * C + n : nullptr;
+    if (m < C + Kc) return dws + (size_t)(m - C) * C + n;
+    return nullptr;
+  }
+  __device__ __forceinline__ float *db(int m) const {
+    if (m < C) return dxo.p ? dbr + m : nullptr;
+    if (m < C + Kc) return dbs + (m - C);
+    return nullptr;
+  }
+};
+
+// head: dW[m][n] += sum A[m][s] * in[n][s]
+template <int IN>
+struct WgDenseOp {
+  int t_begin, t_end, M, N;
+  Act aact, xact;
+  float *dwm, *dbv;
+  __device__ __forceinline__ float a(int b, int m, int t) const {
+    return m < M ? *aact.at(b, m, t) : 0.f;
+  }
+  __device__ __forceinline__ float x(int b, int n, int t) const {
+    if (n >= N) return 0.f;
+    const float v = *xact.at(b, n, t);
+    return IN == IN_LRELU ? leaky(v) : v;
+  }
+  __device__ __forceinline__ float *dw(int m, int n) const {
+    return (m < M && n < N) ? dwm + (size_t)m * N + n : nullptr;
+  }
+  __device__ __forceinline__ float *db(int m) const { return m < M ? dbv + m : nullptr; }
+};
+
+// ======================================================================
+// element-wise kernels
+// ======================================================================
+// causal conv on a one-hot input = two embedding rows (modules.py:28-30)
+__global__ void embed_kernel(const float *__restrict__ cw, const int32_t *__restrict__ idx,
+                             int idx_stride, Act x0, int C, int Q, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const int32_t *ib = idx + (size_t)b * idx_stride;
+  const int q1 = min(max(ib[t], 0), Q - 1);
+  float v = cw[((size_t)c * Q + q1) * 2 + 1];
+  if (t > 0) v += cw[((size_t)c * Q + min(max(ib[t - 1], 0), Q - 1)) * 2 + 0];
+  *x0.at(b, c, t) = v;
+}
+
+__global__ void embed_grad_kernel(float *__restrict__ dcw, const int32_t *__restrict__ idx,
+                                  int idx_stride, Act dx0, int C, int Q, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const int32_t *ib = idx + (size_t)b * idx_stride;
+  const float g = *dx0.at(b, c, t);
+  atomicAdd(dcw + ((size_t)c * Q + min(max(ib[t], 0), Q - 1)) * 2 + 1, g);
+  if (t > 0) atomicAdd(dcw + ((size_t)c * Q + min(max(ib[t - 1], 0), Q - 1)) * 2 + 0, g);
+}
+
+// softmax over channels, in place; one thread per (b, column)
+__global__ void softmax_kernel(float *__restrict__ y, int Q, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (s >= S) return;
+  float *col = y + (size_t)b * Q * S + s;
+  float m = -INFINITY;
+  for (int q = 0; q < Q; ++q) m = fmaxf(m, col[(size_t)q * S]);
+  float sum = 0.f;
+  for (int q = 0; q < Q; ++q) {
+    const float e = expf(col[(size_t)q * S] - m);
+    col[(size_t)q * S] = e;
+    sum += e;
+  }
+  for (int q = 0; q < Q; ++q) col[(size_t)q * S] = col[(size_t)q * S] / sum;
+}
+
+// dlogit = normalize ? p * (dout - sum_q dout*p) : dout ; zero for columns >= S_out
+__global__ void softmax_bwd_kernel(const float *__restrict__ p, const float *__restrict__ dout,
+                                   Act dlogit, int Q, int S_out, int S, int normalize) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (s >= S) return;
+  if (s >= S_out) {
+    for (int q = 0; q < Q; ++q) *dlogit.at(b, q, s) = 0.f;
+    return;
+  }
+  const float *pc = p + (size_t)b * Q * S_out + s, *dc = dout + (size_t)b * Q * S_out + s;
+  float dot = 0.f;
+  if (normalize)
+    for (int q = 0; q < Q; ++q) dot += dc[(size_t)q * S_out] * pc[(size_t)q * S_out];
+  for (int q = 0; q < Q; ++q) {
+    const float d = dc[(size_t)q * S_out];
+    *dlogit.at(b, q, s) = normalize ? pc[(size_t)q * S_out] * (d - dot) : d;
+  }
+}
+
+// dilation queues <- saved layer inputs (state layout: generate.hip ring_offset)
+__global__ void ring_fill_kernel(const float *__restrict__ acts, long long act_stride, Act view,
+                                 float *__restrict__ state, long long state_per_seq, int C,
+                                 int layer_size, int L, int t_last) {
+  // one block per (layer, b); thread over (slot, c)
+  const int l = blockIdx.x, b = blockIdx.y;
+  const int d = 1 << (l % layer_size);
+  const int stack = l / layer_size, pos = l - stack * layer_size;
+  const int off = C * (stack * ((1 << layer_size) - 1) + ((1 << pos) - 1));
+  const float *x = acts + (size_t)l * act_stride;
+  for (int i = threadIdx.x; i < d * C; i += blockDim.x) {
+    const int c = i / d, j = i - c * d;  // j-th most recent time
+    const int t = t_last - j;
+    if (t < 0) continue;
+    state[(size_t)b * state_per_seq + off + (t & (d - 1)) * C + c] =
+        x[(size_t)b * view.sb + (size_t)c * view.ld + t];
+  }
+}
+
+// ======================================================================
+// host orchestration
+// ======================================================================
+struct Geometry {
+  int L, C, Kc, Q, T, Tp, S, Sp, rf;
+  long long act;   // floats per (B,C,Tp) tensor
+  long long skp;   // floats per (B,Kc,Sp)
+  long long hid;   // floats per (B,Q,Sp)
+};
+
+static int make_geometry(const mvn_dims *d, int batch, int t_len, Geometry &g) {
+  int rc = validate_dims(d);
+  if (rc) return rc;
+  if (batch < 0 || t_len < 1) {
+    set_error("batch %d / t_len %d out of range", batch, t_len);
+    return MVN_ERR_BAD_ARG;
+  }
+  g.L = n_layers(d);
+  g.C = d->residual_channels;
+  g.Kc = d->skip_channels;
+  g.Q = d->input_channels;
+  g.T = t_len;
+  g.rf = (int)(dilation_sum(d) + d->stack_size);
+  g.S = mvn_output_size(d, t_len);
+  if (g.S < 0) return g.S;
+  g.Tp = mvn_padded_len(t_len);
+  g.Sp = mvn_padded_len(g.S);
+  g.act = (long long)batch * g.C * g.Tp;
+  g.skp = (long long)batch * g.Kc * g.Sp;
+  g.hid = (long long)batch * g.Q * g.Sp;
+  return MVN_OK;
+}
+
+static Act act_view(float *p, int batch, int ch, int ld) {
+  Act a;
+  a.p = p;
+  a.sb = (long long)ch * ld;
+  a.ld = ld;
+  return a;
+}
+
+template <class Op>
+static void launch_gemm(const Op &op, int m_rows, int batch, hipStream_t s) {
+  const int nt = op.t_end - op.t_begin;
+  if (nt <= 0 || batch <= 0) return;
+  dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
+  hipLaunchKernelGGL(gemm_wx_kernel<Op>, grid, dim3(256), 0, s, op);
+}
+
+template <class Op>
+static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, hipStream_t s) {
+  const int nt = op.t_end - op.t_begin;
+  if (nt <= 0 || batch <= 0) return;
+  const int chunks = (nt + WG_CHUNK - 1) / WG_CHUNK;
+  const int mb = (m_rows + 63) / 64, nb = (n_rows + 63) / 64;
+  dim3 grid(chunks * batch, mb * nb);
+  hipLaunchKernelGGL(wgrad_kernel<Op>, grid, dim3(256), 0, s, op, nb, chunks);
+}
+
+}  // namespace mvn
+
+using namespace mvn;
+
+extern "C" {
+
+int mvn_padded_len(int n) { return n <= 0 ? 0 : (n + 63) / 64 * 64; }
+
+int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index, int index_stride,
+                int batch, int t_len, const mvn_fwd_buffers *buf, float *out, int normalize,
+                int remove_last, int save, void *stream_) {
+  Geometry g;
+  int rc = make_geometry(dims, batch, t_len, g);
+  if (rc) return rc;
+  if (!p || !index || !buf || !buf->acts || !buf->z || !buf->skip || !buf->a1 ||
+      (save && (!buf->th || !buf->sg)) || index_stride < t_len) {
+    set_error("mvn_forward: NULL buffer or bad index stride");
+    return MVN_ERR_BAD_ARG;
+  }
+  const int S_out = g.S - (remove_last ? 1 : 0);
+  if (S_out > 0 && !out) {
+    set_error("mvn_forward: out is NULL");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0) return MVN_OK;
+  hipStream_t s = (hipStream_t)stream_;
+  const int C = g.C, Kc = g.Kc, Q = g.Q, T = g.T;
+  const int t_skip0 = g.rf - 1;
+
+  Act x0 = act_view(buf->acts, batch, C, g.Tp);
+  hipLaunchKernelGGL(embed_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, p->causal_w,
+                     index, index_stride, x0, C, Q, T);
+  Act zv = act_view(buf->z, batch, C, g.Tp);
+  Act skipv = act_view(buf->skip, batch, Kc, g.Sp);
+  int A = 0;  // first valid time of the current layer's input
+  for (int l = 0; l < g.L; ++l) {
+    const int d = dilation_of(dims, l);
+    const int src = save ? l : (l & 1), dst = save ? l + 1 : ((l + 1) & 1);
+    Act xin = act_view(buf->acts + (size_t)src * g.act, batch, C, g.Tp);
+    Act xout = act_view(buf->acts + (size_t)dst * g.act, batch, C, g.Tp);
+    FgOp f;
+    f.K = 2 * C; f.t_begin = A + d; f.t_end = T; f.C = C; f.d = d;
+    f.wf = p->filter_w[l]; f.wg = p->gate_w[l];
+    f.xin = xin; f.z = zv;
+    f.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+    f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+    launch_gemm(f, 2 * ((C + 31) / 32 * 32), batch, s);
+    RsOp r;
+    r.K = C; r.t_begin = A + d; r.t_end = T; r.C = C; r.Kc = Kc; r.t_skip0 = t_skip0;
+    r.wr = p->residual_w[l]; r.br = p->residual_b[l]; r.ws = p->skip_w[l]; r.bs = p->skip_b[l];
+    r.z = zv; r.xin = xin; r.xout = xout; r.skip = skipv; r.first_layer = (l == 0);
+    if (l == g.L - 1) r.xout.p = nullptr;  // the last residual output is never used
+    launch_gemm(r, C + Kc, batch, s);
+    A += d;
+  }
+  // head: a1 = lrelu(W1 lrelu(skip) + b1); logits = W2 a1 + b2   (columns s = 0..S-1)
+  Act a1v = act_view(buf->a1, batch, Q, g.Sp);
+  {
+    DenseOp<IN_LRELU, OUT_BIAS_LRELU, false> h1;
+    h1.K = Kc; h1.t_begin = 0; h1.t_end = g.S; h1.M = Q; h1.wmat = p->head1_w; h1.ldw = Kc;
+    h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v; h1.t_out_end = g.S;
+    launch_gemm(h1, Q, batch, s);
+  }
+  if (S_out > 0) {
+    DenseOp<IN_ID, OUT_BIAS, false> h2;
+    h2.K = Q; h2.t_begin = 0; h2.t_end = g.S; h2.M = Q; h2.wmat = p->head2_w; h2.ldw = Q;
+    h2.bias = p->head2_b; h2.xin = a1v; h2.yout = act_view(out, batch, Q, S_out); h2.ref = a1v;
+    h2.t_out_end = S_out;
+    launch_gemm(h2, Q, batch, s);
+    if (normalize)
+      hipLaunchKernelGGL(softmax_kernel, dim3((S_out + 255) / 256, batch), dim3(256), 0, s, out, Q,
+                         S_out);
+  }
+  return check_hip(hipGetLastError(), "mvn_forward");
+}
+
+int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grads *gr,
+                 const int32_t *index, int index_stride, int batch, int t_len,
+                 const mvn_fwd_buffers *fwd, const mvn_bwd_buffers *bwd, const float *out,
+                 const float *dout, int normalize, int remove_last, void *stream_) {
+  Geometry g;
+  int rc = make_geometry(dims, batch, t_len, g);
+  if (rc) return rc;
+  if (!p || !gr || !index || !fwd || !bwd || !fwd->acts || !fwd->th || !fwd->sg || !fwd->skip ||
+      !fwd->a1 || !bwd->dx_a || !bwd->dx_b || !bwd->dfg || !bwd->dskip || !bwd->da1 ||
+      !bwd->dlogit || !dout || (normalize && !out)) {
+    set_error("mvn_backward: NULL buffer");
+    return MVN_ERR_BAD_ARG;
+  }
+  const int S_out = g.S - (remove_last ? 1 : 0);
+  if (batch == 0 || S_out <= 0) return MVN_OK;
+  hipStream_t s = (hipStream_t)stream_;
+  const int C = g.C, Kc = g.Kc, Q = g.Q, T = g.T;
+  const int t_skip0 = g.rf - 1;
+
+  Act dlog = act_view(bwd->dlogit, batch, Q, g.Sp);
+  Act da1 = act_view(bwd->da1, batch, Q, g.Sp);
+  Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
+  Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
+  Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((g.S + 255) / 256, batch), dim3(256), 0, s, out, dout,
+                     dlog, Q, S_out, g.S, normalize);
+  {  // head conv2: weight grad, then data grad (x lrelu'(a1))
+    WgDenseOp<IN_ID> w2;
+    w2.t_begin = 0; w2.t_end = g.S; w2.M = Q; w2.N = Q; w2.aact = dlog; w2.xact = a1v;
+    w2.dwm = gr->head2_w; w2.dbv = gr->head2_b;
+    launch_wgrad(w2, Q, Q, batch, s);
+    DenseOp<IN_ID, OUT_MUL_DLRELU, true> d2;
+    d2.K = Q; d2.t_begin = 0; d2.t_end = g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
+    d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.S;
+    launch_gemm(d2, Q, batch, s);
+  }
+  {  // head conv1
+    WgDenseOp<IN_LRELU> w1;
+    w1.t_begin = 0; w1.t_end = g.S; w1.M = Q; w1.N = Kc; w1.aact = da1; w1.xact = skipv;
+    w1.dwm = gr->head1_w; w1.dbv = gr->head1_b;
+    launch_wgrad(w1, Q, Kc, batch, s);
+    DenseOp<IN_ID, OUT_MUL_DLRELU, true> d1;
+    d1.K = Q; d1.t_begin = 0; d1.t_end = g.S; d1.M = Kc; d1.wmat = p->head1_w; d1.ldw = Kc;
+    d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.S;
+    launch_gemm(d1, Kc, batch, s);
+  }
+  // layers, last to first
+  int A_lo[4096];
+  {
+    int A = 0;
+    for (int l = 0; l <= g.L && l < 4096; ++l) {
+      A_lo[l] = A;
+      if (l < g.L) A += dilation_of(dims, l);
+    }
+  }
+  float *dxo_p = nullptr;  // gradient w.r.t. the layer's residual output
+  float *cur = bwd->dx_a, *nxt = bwd->dx_b;
+  Act dfg = act_view(bwd->dfg, batch, 2 * C, g.Tp);
+  for (int l = g.L - 1; l >= 0; --l) {
+    const int d = dilation_of(dims, l);
+    const int t_lo = A_lo[l + 1];
+    Act th = act_view(fwd->th + (size_t)l * g.act, batch, C, g.Tp);
+    Act sg = act_view(fwd->sg + (size_t)l * g.act, batch, C, g.Tp);
+    Act xin = act_view(fwd->acts + (size_t)l * g.act, batch, C, g.Tp);
+    Act dxo = act_view(dxo_p, batch, C, g.Tp);
+    WgRsOp wr;
+    wr.t_begin = t_lo; wr.t_end = T; wr.C = C; wr.Kc = Kc; wr.t_skip0 = t_skip0;
+    wr.dxo = dxo; wr.dskip = dskip; wr.th = th; wr.sg = sg;
+    wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
+    wr.dbs = gr->skip_b[l];
+    launch_wgrad(wr, C + Kc, C, batch, s);
+    DzOp dz;
+    dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
+    dz.wr = p->residual_w[l]; dz.ws = p->skip_w[l];
+    dz.dxo = dxo; dz.dskip = dskip; dz.th = th; dz.sg = sg; dz.dfg = dfg;
+    launch_gemm(dz, C, batch, s);
+    WgFgOp wf;
+    wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin;
+    wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
+    launch_wgrad(wf, 2 * C, 2 * C, batch, s);
+    DxOp dx;
+    dx.K = 4 * C; dx.t_begin = A_lo[l]; dx.t_end = T; dx.C = C; dx.d = d; dx.t_lo = t_lo;
+    dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];
+    dx.dxo = dxo; dx.dfg = dfg; dx.dxi = act_view(cur, batch, C, g.Tp);
+    launch_gemm(dx, C, batch, s);
+    dxo_p = cur;
+    float *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  hipLaunchKernelGGL(embed_grad_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s,
+                     gr->causal_w, index, index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T);
+  return check_hip(hipGetLastError(), "mvn_backward");
+}
+
+int mvn_gen_prime_from_forward(const mvn_dims *dims, const mvn_fwd_buffers *fwd, int batch,
+                               int t_len, float *state, void *stream_) {
+  Geometry g;
+  int rc = make_geometry(dims, batch, t_len, g);
+  if (rc) return rc;
+  if (!fwd || !fwd->acts || !state) {
+    set_error("mvn_gen_prime_from_forward: NULL buffer");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0) return MVN_OK;
+  // steps t = 0 .. t_len-2 have been consumed: queue l holds x_l[t] for the
+  // d_l most recent t <= t_len-2, all of them >= A_l because t_len >= RF
+  Act view = act_view(fwd->acts, batch, g.C, g.Tp);
+  hipLaunchKernelGGL(ring_fill_kernel, dim3(g.L, batch), dim3(256), 0, (hipStream_t)stream_,
+                     fwd->acts, g.act, view, state, dilation_sum(dims) * g.C, g.C,
+                     dims->layer_size, g.L, t_len - 2);
+  return check_hip(hipGetLastError(), "mvn_gen_prime_from_forward");
+}
+
+}  // extern "C"

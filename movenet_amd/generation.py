@@ -100,9 +100,11 @@ class RingGenerator:
             self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
         self.t = 0          # number of time steps consumed so far
         self.n_given = 1
+        self.prime_with_forward = True
         self.repack(state_dict)
 
     def repack(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        self._sd = state_dict
         params, keep = pack_params(self.dims, state_dict, self.n_layers)
         with torch.cuda.device(self.device):
             N.check(self.lib.mvn_gen_pack_weights(self.dims, self.variant, params,
@@ -139,7 +141,18 @@ class RingGenerator:
         self.samples.zero_()
         self.samples[:, :P] = prompt_idx.to(torch.int32)
         self.n_given = P
-        self._run(0, P - 1, P)
+        if self.prime_with_forward and P >= self.rf:
+            # one full-sequence forward over the prompt (MFMA kernels), then copy
+            # each layer's most recent d_l inputs into its queue
+            from .ops import run_forward
+            idx = self.samples[:, :P].contiguous()
+            _, buf = run_forward(self.dims, self._sd, idx, False, False, save=True)
+            with torch.cuda.device(self.device):
+                N.check(self.lib.mvn_gen_prime_from_forward(
+                    self.dims, buf.struct, self.batch, P, self.state.data_ptr(),
+                    _stream_ptr(self.device)), "mvn_gen_prime_from_forward")
+        else:
+            self._run(0, P - 1, P)
         self.t = P - 1
 
     def advance(self, n_new: int) -> None:

@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol that
+include/movenet_hip.h declares; host-side shape arithmetic and error mapping."""
+import os
+import re
+
+import pytest
+
+from movenet_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "movenet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 10
+    lib = N.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in movenet_hip.h but not exported"
+    assert sorted(N.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.mvn_abi_version() == 1
+
+
+def test_receptive_fields_and_output_size():
+    lib = N.lib()
+    d2 = N.make_dims(10, 3, 256, 64, 64)
+    assert lib.mvn_receptive_fields(d2) == 3072
+    assert lib.mvn_receptive_fields(N.make_dims(10, 6, 256, 128, 128)) == 6144
+    assert lib.mvn_receptive_fields(N.make_dims(2, 2, 64, 16, 16)) == 8
+    assert lib.mvn_output_size(d2, 3072) == 1
+    assert lib.mvn_output_size(d2, 16000) == 16000 - 3072 + 1
+    rc = lib.mvn_output_size(d2, 3071)
+    assert rc == N.MVN_ERR_TOO_SHORT
+    with pytest.raises(ValueError, match="receptive"):
+        N.check(rc, "mvn_output_size")
+    assert lib.mvn_receptive_fields(N.make_dims(0, 3, 256, 64, 64)) == N.MVN_ERR_BAD_DIMS
+
+
+def test_generate_sizes_and_variants():
+    lib = N.lib()
+    d2 = N.make_dims(10, 3, 256, 64, 64)
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO) == N.GEN_STREAM
+    d1 = N.make_dims(2, 2, 64, 16, 16)
+    assert lib.mvn_gen_variant(d1, N.GEN_AUTO) == N.GEN_GENERIC
+    assert lib.mvn_gen_variant(d1, N.GEN_STREAM) == N.MVN_ERR_UNSUPPORTED
+    # audio-path parameters of the 30-layer model
+    assert lib.mvn_gen_weights_floats(d2, N.GEN_GENERIC) == 856320
+    assert lib.mvn_gen_weights_floats(d2, N.GEN_STREAM) == 856320
+    # dilation queues: D*C floats per sequence (786 KB fp32)
+    assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64
+    assert lib.mvn_gen_state_floats(d2, 16) == 16 * 3069 * 64
+
+
+def test_bad_arguments_are_refused_before_any_launch():
+    lib = N.lib()
+    d2 = N.make_dims(10, 3, 256, 64, 64)
+    rc = lib.mvn_generate(d2, 0, None, None, None, 1, 10, 10, 1, 0, 5, 0.0, 0, None, None, 0, None)
+    assert rc == N.MVN_ERR_BAD_ARG
+    with pytest.raises(ValueError):
+        N.check(rc, "mvn_generate")
+    assert "bad argument" in N.last_error()

@@ -1,0 +1,136 @@
+"""GPU parity of the full-sequence forward/backward (MFMA kernels through the
+C ABI, wrapped in movenet_amd.WaveNet.forward) against the golden vectors from
+the reference.
+
+Tolerances: logits within 2e-5 of the logit range, probabilities within 2e-6
+absolute, loss within 2e-6, gradients within 2e-4 relative to the tensor's
+largest entry (fp32 sums over up to B*T = 6400 positions in another order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import cfg_of, one_hot, rel_err, synthetic_indices, weights_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_TOL = 2e-5
+
+
+def _model(cfg, sd):
+    from movenet_amd.wavenet import WaveNet
+    m = WaveNet(**cfg)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+def test_g1_small_forward_flags_and_shapes(golden):
+    fx = golden("g1_small_forward.npz")
+    cfg, dims, sd = weights_of(fx)
+    Q, T = cfg["input_channels"], int(fx["T"])
+    x = one_hot(synthetic_indices(int(fx["B"]), T, Q, int(fx["idx_seed"])), Q).to(DEV)
+    m = _model(cfg, sd)
+    with torch.no_grad():
+        logits = m(x, output_unnormalized=False, remove_last=False)
+        probs = m(x)  # default: softmax probabilities, last column dropped (Q1)
+        logits_rl = m(x, output_unnormalized=False)
+    assert logits.shape == fx["logits"].shape and probs.shape == fx["probs"].shape
+    assert rel_err(logits.cpu(), fx["logits"]) < LOGIT_TOL
+    assert np.abs(probs.cpu().numpy() - fx["probs"]).max() < 2e-6
+    assert torch.equal(logits_rl, logits[:, :, :-1])
+    assert torch.allclose(probs.sum(1), torch.ones_like(probs.sum(1)), atol=1e-5)
+    with pytest.raises(ValueError, match="receptive"):
+        m(x[:, :, :dims.receptive_fields - 1])
+    # exactly RF samples: one output column, zero after remove_last
+    assert m(x[:, :, :dims.receptive_fields], remove_last=False).shape[2] == 1
+    assert m(x[:, :, :dims.receptive_fields]).shape[2] == 0
+
+
+def test_g2_l30_forward(golden):
+    fx = golden("g2_l30_forward.npz")
+    cfg, dims, sd = weights_of(fx)
+    x = one_hot(synthetic_indices(int(fx["B"]), int(fx["T"]), 256, int(fx["idx_seed"])), 256).to(DEV)
+    m = _model(cfg, sd)
+    with torch.no_grad():
+        logits = m(x, output_unnormalized=False, remove_last=False)
+    assert rel_err(logits.cpu(), fx["logits"]) < LOGIT_TOL
+    ws = int(fx["window_start"])
+    with torch.no_grad():
+        win = m(x[:, :, ws:ws + dims.receptive_fields], output_unnormalized=False, remove_last=False)
+    assert rel_err(win.cpu(), fx["window_logits"]) < LOGIT_TOL
+
+
+def test_g6_l60_c128_forward(golden):
+    fx = golden("g6_l60_forward.npz")
+    cfg, dims, sd = weights_of(fx)
+    x = one_hot(synthetic_indices(1, int(fx["T"]), 256, int(fx["idx_seed"])), 256).to(DEV)
+    with torch.no_grad():
+        logits = _model(cfg, sd)(x, output_unnormalized=False, remove_last=False)
+    assert rel_err(logits.cpu(), fx["logits"]) < LOGIT_TOL
+
+
+@pytest.mark.parametrize("name", ["g4_small_train.npz", "g4_l30_train.npz"])
+def test_g4_trainer_arithmetic_and_gradients(golden, name):
+    """loss = cross_entropy(PROBABILITIES, target) as in
+    pytorch_lightning_trainer.py:62-66 (Q2), gradients via the HIP backward."""
+    fx = golden(name)
+    cfg, dims, sd = weights_of(fx)
+    Q = cfg["input_channels"]
+    x = one_hot(synthetic_indices(int(fx["B"]), int(fx["T"]), Q, int(fx["idx_seed"])), Q).to(DEV)
+    m = _model(cfg, sd).train()
+    out = m(x)
+    target = x[:, :, m.receptive_fields:].argmax(1)
+    loss = F.cross_entropy(out, target)
+    acc = (out.argmax(1) == target).float().mean()
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) < 2e-6
+    assert abs(acc.item() - float(fx["acc"])) < 1e-6
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    names = [str(n) for n in fx["grad_names"]]
+    assert sorted(grads) == names  # same set of parameters receives a gradient
+    got = np.array([grads[n].norm().item() for n in names])
+    assert np.allclose(got, fx["grad_norms"], rtol=2e-4, atol=1e-12), \
+        np.abs(got / fx["grad_norms"] - 1).max()
+    L = dims.n_layers
+    for key, pname in (("grad_causal", "causal_conv.conv.weight"),
+                       ("grad_l0_filter", "residual_conv_stack.conv_layers.0.conv_filter.conv.weight"),
+                       ("grad_last_skip_w", f"residual_conv_stack.conv_layers.{L - 1}.conv_skip.weight"),
+                       ("grad_head2_b", "dense_conv.conv2.bias")):
+        assert rel_err(grads[pname].cpu(), fx[key]) < 2e-4, key
+
+
+def test_forward_priming_equals_step_priming(golden):
+    """The dilation queues filled from one full-sequence forward equal those
+    built by stepping the generator over the prompt."""
+    from movenet_amd.generation import RingGenerator
+    fx = golden("g3_l30_greedy.npz")
+    cfg, dims, sd = weights_of(fx)
+    rf, N_, B = dims.receptive_fields, int(fx["N"]), int(fx["B"])
+    sdd = {k: v.to(DEV) for k, v in sd.items()}
+    pidx = synthetic_indices(B, rf, 256, int(fx["prompt_seed"])).to(DEV)
+    outs = []
+    for use_fwd in (True, False):
+        g = RingGenerator(**cfg, state_dict=sdd, batch=B, n_total=N_, device=DEV)
+        g.prime_with_forward = use_fwd
+        g.prime(pidx)
+        g.advance(N_ - rf)
+        outs.append(g.samples.cpu().numpy())
+    assert np.array_equal(outs[0], fx["indices"]) and np.array_equal(outs[1], fx["indices"])
+
+
+def test_config2_forward_vs_generator_logits_full_batch():
+    """BASELINE config 2 at B=16: two independent HIP implementations (MFMA
+    full-sequence forward, ring-buffer step kernel) agree on the logits."""
+    from movenet_amd.generation import RingGenerator
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=0)
+    rf, B, T = 3072, 16, 3072 + 200
+    idx = synthetic_indices(B, T, 256, 99).to(DEV)
+    m = _model(cfg, sd)
+    with torch.no_grad():
+        logits = m(one_hot(idx.cpu(), 256).to(DEV), output_unnormalized=False, remove_last=True)
+    g = RingGenerator(**cfg, state_dict={k: v.to(DEV) for k, v in sd.items()}, batch=B, n_total=T,
+                      device=DEV)
+    _, glog = g.teacher_forced(idx, logits_t0=rf)  # (B, T-rf, Q)
+    assert rel_err(logits.permute(0, 2, 1).cpu(), glog.cpu()) < LOGIT_TOL

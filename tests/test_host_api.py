@@ -1,0 +1,53 @@
+"""CPU: the drop-in module's host-side contract: ctor,
+attributes, constants, state_dict keys/shapes, shape arithmetic, exceptions,
+and that CPU tensors are refused loudly (no fallback)."""
+import pytest
+import torch
+
+from movenet_amd import wavenet as W
+from movenet_amd.utils.weights import make_state_dict, parameter_shapes
+
+
+def test_constants_and_solver():
+    assert (W.MAX_AUDIO_FRAMES, W.MAX_VIDEO_FRAMES, W.VIDEO_KERNEL_SIZE, W.UPSAMPLE_STRIDE) == \
+        (160000, 160, (1, 64, 64), 10)
+    assert W.upsample_kernel_size_solver(160, 1600, stride=10) == (10,)
+    assert W.upsample_kernel_size_solver(16000, 160000, stride=10) == (10,)
+
+
+def test_state_dict_contract():
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    m = W.WaveNet(**cfg)
+    want = parameter_shapes(**cfg)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(got) == list(want)          # same keys, same registration order
+    assert got == dict(want)
+    assert sum(v.numel() for v in m.state_dict().values()) == 1491200  # SURVEY 2.2 C2 [probed]
+    m.load_state_dict(make_state_dict(**cfg, seed=0), strict=True)
+    for attr in ("layer_size", "stack_size", "input_channels", "residual_channels", "skip_channels"):
+        assert getattr(m, attr) == cfg[attr]
+    assert m.receptive_fields == 3072
+    assert m.residual_conv_stack.dilations[:11] == [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1]
+    # Lightning / DDP prefixes are plain key prefixes
+    pref = {"model." + k: v for k, v in m.state_dict().items()}
+    m.load_state_dict({k[len("model."):]: v for k, v in pref.items()})
+
+
+def test_default_ctor_and_output_size():
+    m = W.WaveNet(2, 2, 64)
+    assert (m.residual_channels, m.skip_channels) == (16, 16)
+    assert m.receptive_fields == 8
+    x = torch.zeros(1, 64, 8)
+    assert m.compute_output_size(x) == 1
+    with pytest.raises(ValueError, match="receptive"):
+        m.compute_output_size(torch.zeros(1, 64, 7))
+
+
+def test_cpu_tensors_are_refused():
+    m = W.WaveNet(2, 2, 64)
+    x = torch.zeros(1, 64, 16)
+    x[:, 0] = 1
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.generate(x, n_samples=20, temperature=0.0)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(x)
