@@ -111,6 +111,62 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
     }
 
 
+def train_leg(dev, world, rank, steps=3, warmup=1, batch=16, t_len=16000):
+    """Secondary metric M2 (BASELINE.json): train-step tokens/sec on config 2 --
+    forward (probabilities), cross_entropy on them (Q2), backward through the HIP
+    kernels, one flat gradient all-reduce when world > 1, AdamW.  Token = one
+    (sequence, time) position with a target: B * (T - RF)."""
+    import torch.nn.functional as F
+    from movenet_amd.parallel import FlatGradSync
+    from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices
+    from movenet_amd.wavenet import WaveNet
+    model = WaveNet(**CFG)
+    model.load_state_dict(make_state_dict(**CFG, seed=0))
+    model.to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    sync = FlatGradSync(model.parameters(), world)
+    sync.broadcast_parameters(0)
+    Q, rf = CFG["input_channels"], 3072
+    audio = one_hot(synthetic_indices(batch, t_len, Q, 1234 + rank).to(dev), Q)
+    target = audio[:, :, rf:].argmax(1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model(audio), target)
+        loss.backward()
+        sync.sync_gradients()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tokens = world * batch * (t_len - rf) * steps
+    # SURVEY.md section 8d: 5,441,508 FLOP per token (fwd + bwd = 3 x forward MACs x 2)
+    flop_per_token = 5441508
+    tf = tokens * flop_per_token / dt / 1e12
+    return {"metric": "train-step tokens/sec", "value": tokens / dt, "unit": "tokens/s",
+            "ms_per_step": dt / steps * 1e3, "global_batch": world * batch, "seq_len": t_len,
+            "tokens_per_step": world * batch * (t_len - rf), "optimizer": "AdamW", "dtype": "f32",
+            "loss": float(loss.detach()),
+            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": FP32_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / world / FP32_MATRIX_PEAK_TFLOPS}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +175,7 @@ def main():
     ap.add_argument("--new-samples", type=int, default=16000, help="samples per sequence per step")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,11 +242,22 @@ def main():
         elapsed = float(t.item())
 
     assert gen.t == rf - 1 + (K + W) * n_new
+    variant_used = gen.variant
     total_samples = world * BATCH * n_new * K
     value = total_samples / elapsed
     avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
     flops_per_launch = flop_per_sample(CFG) * BATCH * n_new
     achieved = flops_per_launch / avg_kernel_s / 1e12
+
+    train = None
+    if not args.no_train_leg:
+        try:
+            del gen
+            torch.cuda.empty_cache()
+            train = train_leg(dev, world, rank)
+            log(f"rank {rank}: train leg {train['value']:.0f} tokens/s")
+        except Exception as e:  # the headline metric must survive a failure here
+            train = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         out = {
@@ -211,7 +279,7 @@ def main():
                 "batch_per_gpu": BATCH,
                 "new_samples_per_sequence_per_step": n_new,
                 "prompt": rf,
-                "kernel_variant": {1: "generic", 2: "stream64"}[gen.variant],
+                "kernel_variant": {1: "generic", 2: "stream64"}[variant_used],
                 "parallelism": f"independent clips x{world} (no collective)",
             },
             "samples_per_s_per_gpu": value / world,
@@ -225,12 +293,13 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
                 "traffic": None,
-                "kernel": "gen_stream64_kernel" if gen.variant == 2 else "gen_generic_kernel",
+                "kernel": "gen_stream64_kernel" if variant_used == 2 else "gen_generic_kernel",
                 "flop_per_launch": flops_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,
                 "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",
             },
         }
+        out["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(sd_cpu)
             out["cpu_baseline"] = cb

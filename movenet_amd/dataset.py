@@ -1,0 +1,132 @@
+"""Batches for the trainer entry point.
+
+The reference's loader decodes Kinetics mp4 clips (movenet/dataset.py:59-364:
+torchvision.io + torchaudio + pytorchvideo), none of which exist offline; that
+storage/codec side is out of scope.  What the trainer
+consumes is the ``Batch`` tuple ``(audio one-hot (B,Q,T), video|None, contexts,
+filepaths, info)`` (dataset.py:186-203) and that contract is kept here, fed by
+a synthetic source:
+
+    --dataset synthetic://clips=64,frames=16000,seed=1234
+
+Class indices are U{0..Q-1} (SURVEY.md section 8d "Synthetic inputs"); the
+optional random contiguous crop ``batch_subsample_frac`` follows
+dataset.py:232-242.
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Iterator, List, Optional
+
+import numpy as np
+import torch
+
+from .utils.weights import one_hot
+
+
+class Batch:
+    def __init__(self, audio, video, contexts, filepaths, info):
+        self.audio, self.video = audio, video
+        self.contexts, self.filepaths, self.info = contexts, filepaths, info
+
+    def pin_memory(self):
+        self.audio = self.audio.pin_memory()
+        if self.video is not None:
+            self.video = self.video.pin_memory()
+        return self
+
+    def __iter__(self):
+        yield from (self.audio, self.video, self.contexts, self.filepaths, self.info)
+
+
+def parse_synthetic(spec: str) -> dict:
+    if not spec.startswith("synthetic://"):
+        raise ValueError(
+            f"dataset {spec!r}: only synthetic://clips=N,frames=T[,seed=S] sources are built; "
+            "the Kinetics mp4 decoder of the reference is out of scope (SURVEY.md section 2)")
+    out = dict(clips=8, frames=16000, seed=1234)
+    body = spec[len("synthetic://"):]
+    for item in filter(None, body.split(",")):
+        k, v = item.split("=")
+        out[k.strip()] = int(v)
+    return out
+
+
+class SyntheticLoader:
+    """Deterministic, shardable replacement for DataLoader(KineticsDataset)."""
+
+    def __init__(self, spec: str, input_channels: int, batch_size: int, train: bool = True,
+                 rank: int = 0, world_size: int = 1, shuffle: bool = False,
+                 batch_subsample_frac: Optional[float] = None, **_ignored):
+        cfg = parse_synthetic(spec)
+        self.n_clips, self.frames = cfg["clips"], cfg["frames"]
+        self.seed = cfg["seed"] + (0 if train else 10007)
+        self.Q, self.batch_size = input_channels, batch_size
+        self.rank, self.world = rank, max(world_size, 1)
+        self.shuffle, self.frac = shuffle, batch_subsample_frac
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def _order(self) -> List[int]:
+        order = list(range(self.n_clips))
+        if self.shuffle:
+            random.Random(self.seed + self.epoch).shuffle(order)
+        # DistributedSampler semantics: pad to a multiple of world, stride by rank
+        per = math.ceil(len(order) / self.world)
+        order = (order + order[: per * self.world - len(order)])[self.rank::self.world]
+        return order
+
+    def __len__(self) -> int:
+        return math.ceil(len(self._order()) / self.batch_size)
+
+    def _clip(self, i: int) -> torch.Tensor:
+        rng = np.random.default_rng(self.seed * 1000003 + i)
+        return torch.from_numpy(rng.integers(0, self.Q, size=self.frames, dtype=np.int64))
+
+    def __iter__(self) -> Iterator[Batch]:
+        order = self._order()
+        crop_rng = random.Random(self.seed * 31 + self.epoch * 7 + self.rank)
+        for s in range(0, len(order), self.batch_size):
+            ids = order[s:s + self.batch_size]
+            idx = torch.stack([self._clip(i) for i in ids])
+            audio = one_hot(idx, self.Q)
+            if self.frac is not None:
+                n = math.ceil(audio.shape[-1] * self.frac)
+                start = crop_rng.randint(0, audio.shape[-1] - n)
+                audio = audio[..., start:start + n]
+            yield Batch(audio, None, ["synthetic"] * len(ids),
+                        [f"synthetic://{i}" for i in ids],
+                        [dict(video_fps=0.0, audio_fps=float(self.frames) / 10.0)] * len(ids))
+
+
+def get_dataloader(filepath, input_channels: int, batch_size: int = 64, train: bool = True,
+                   rank: int = 0, world_size: int = 0, use_video: bool = True,
+                   normalize_audio: bool = True, batch_subsample_frac: Optional[float] = None,
+                   **kwargs) -> SyntheticLoader:
+    """Signature of movenet/dataset.py:59-98."""
+    if use_video:
+        raise NotImplementedError(
+            "video batches are not built: the reference's conditioned forward raises "
+            "(SURVEY.md Q6); pass --use_video 0")
+    return SyntheticLoader(str(filepath), input_channels, batch_size, train=train, rank=rank,
+                           world_size=world_size, shuffle=kwargs.get("shuffle", False),
+                           batch_subsample_frac=batch_subsample_frac)
+
+
+# -- mu-law companding: the formula the project states (RESEARCH.md:156-163).
+# The reference calls torchaudio.functional.mu_law_encoding/decoding, which is
+# absent offline and pinned by no fixture in the reference => PARITY UNPINNED.
+def mu_law_encoding(x: torch.Tensor, quantization_channels: int) -> torch.Tensor:
+    mu = quantization_channels - 1.0
+    x = x.to(torch.float32)
+    y = torch.sign(x) * torch.log1p(mu * torch.abs(x)) / math.log1p(mu)
+    return ((y + 1) / 2 * mu + 0.5).to(torch.int64)
+
+
+def mu_law_decoding(q: torch.Tensor, quantization_channels: int) -> torch.Tensor:
+    mu = quantization_channels - 1.0
+    y = (q.to(torch.float32) / mu) * 2 - 1.0
+    return torch.sign(y) * (torch.exp(torch.abs(y) * math.log1p(mu)) - 1.0) / mu

@@ -1,0 +1,77 @@
+"""GPU: the trainer entry point on BASELINE config 1's model (2x2 layers, Q=64,
+C=K=16, batch 2) follows the same loss trajectory and reaches the same weights
+as the CPU oracle trained with the same batches, optimizer and scheduler.
+Tolerance: losses 2e-6 absolute (they sit at ~ln 64, Q2), weights 1e-4 relative
+after 6 AdamW steps."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+from movenet_amd.config import ModelConfig, TrainingConfig
+from movenet_amd.utils.weights import make_state_dict
+from oracle import wavenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_training_matches_oracle(tmp_path):
+    from movenet_amd.pytorch_lightning_trainer import Dance2Music, Trainer
+    mc = ModelConfig(layer_size=2, stack_size=2, input_channels=64, residual_channels=16,
+                     skip_channels=16)
+    cfg = TrainingConfig(model_config=mc, batch_size=2, val_batch_size=2, n_epochs=2,
+                         use_video=False, optimizer="AdamW", learning_rate=1e-3, weight_decay=0.01,
+                         scheduler="OneCycleLR", max_learning_rate=3e-3, accumulation_steps=1,
+                         model_output_path=tmp_path, gradient_clipping=0.0)
+    spec = "synthetic://clips=6,frames=400,seed=5"
+    sd0 = make_state_dict(2, 2, 64, 16, 16, seed=5)
+    m = Dance2Music(spec, cfg)
+    m.model.load_state_dict(sd0)
+    tr = Trainer(max_epochs=cfg.n_epochs, default_root_dir=tmp_path, gradient_clip_val=0.0,
+                 accumulate_grad_batches=1)
+    tr.fit(m)
+    assert len(tr.history) == 6 and (tmp_path / "checkpoints").exists()
+    ck = torch.load(next((tmp_path / "checkpoints").glob("epoch=1-*.ckpt")), weights_only=True)
+    assert all(k.startswith("model.") for k in ck["state_dict"])
+
+    # the same run on the CPU oracle
+    dims = O.Dims(2, 2, 64, 16, 16)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3, weight_decay=0.01)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-3, epochs=2, steps_per_epoch=3,
+                                              pct_start=cfg.lr_pct_start, three_phase=True)
+    losses = []
+    ref = Dance2Music(spec, cfg)
+    for epoch in range(2):
+        loader = ref.train_dataloader()
+        loader.set_epoch(epoch)
+        for batch in loader:
+            opt.zero_grad(set_to_none=True)
+            out = O.forward(params, dims, batch.audio)
+            target = batch.audio[:, :, dims.receptive_fields:].argmax(1)
+            loss = F.cross_entropy(out, target)
+            loss.backward()
+            opt.step()
+            sch.step()
+            losses.append(loss.item())
+    got = [h["train_loss"] for h in tr.history]
+    assert np.abs(np.array(got) - np.array(losses)).max() < 2e-6, (got, losses)
+    final = m.model.state_dict()
+    for k in ("causal_conv.conv.weight", "residual_conv_stack.conv_layers.1.conv_gate.conv.weight",
+              "residual_conv_stack.conv_layers.3.conv_skip.bias", "dense_conv.conv2.weight"):
+        assert rel_err(final[k].cpu(), params[k].detach()) < 1e-4, k
+    # parameters the audio path never touches stay as initialised (no grad => AdamW skips them)
+    assert torch.equal(final["video_conv.weight"].cpu(), sd0["video_conv.weight"])
+
+
+def test_gradient_accumulation_and_clipping_run(tmp_path):
+    from movenet_amd.pytorch_lightning_trainer import Dance2Music, Trainer
+    cfg = TrainingConfig(model_config=ModelConfig(2, 2, 64, 16, 16), batch_size=2, n_epochs=1,
+                         use_video=False, scheduler=None, accumulation_steps=2,
+                         model_output_path=tmp_path)
+    m = Dance2Music("synthetic://clips=8,frames=200,seed=1", cfg)
+    tr = Trainer(max_epochs=1, default_root_dir=None, gradient_clip_val=1e-3,
+                 accumulate_grad_batches=2)
+    tr.fit(m)
+    assert len(tr.history) == 2 and all(np.isfinite(h["train_loss"]) for h in tr.history)

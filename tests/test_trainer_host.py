@@ -1,0 +1,148 @@
+"""CPU: trainer-side host logic -- CLI flags, config round trip, synthetic
+batches, optimizer/scheduler factories, and the world_size-2 data-parallel
+gradient exchange over gloo."""
+import json
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from movenet_amd.config import ModelConfig, TrainingConfig, arg_parser, config_from_args
+from movenet_amd.dataset import get_dataloader, mu_law_decoding, mu_law_encoding
+
+
+def test_cli_defaults_match_reference_parser():
+    # defaults of /root/reference/movenet/config.py:149-240
+    a = arg_parser().parse_args([])
+    assert (a.batch_size, a.val_batch_size, a.optimizer, a.learning_rate) == (3, 3, "AdamW", 0.001)
+    assert (a.input_channels, a.residual_channels, a.skip_channels, a.layer_size, a.stack_size) == \
+        (16, 16, 8, 3, 3)
+    assert a.scheduler is None and a.lr_pct_start == 0.45 and a.max_learning_rate == 0.003
+    assert a.use_video is True and a.dist_backend == "nccl" and a.dist_port == "8888"
+    assert a.n_epochs == 10 and a.accumulation_steps == 1 and a.gradient_clipping == 0.0
+
+
+def test_config_from_args_and_q11_quirk():
+    a = arg_parser().parse_args(
+        "--dataset synthetic://clips=4,frames=100 --use_video 0 --input_channels 64 "
+        "--residual_channels 16 --skip_channels 16 --layer_size 2 --stack_size 2 --batch_size 2 "
+        "--n_epochs 1 --gradient_clipping 5.0 --scheduler_milestones [1,2] --optimizer SGD".split())
+    c = config_from_args(a)
+    assert c.model_config == ModelConfig(2, 2, 64, 16, 16)
+    assert c.use_video is False and c.batch_size == 2 and c.optimizer == "SGD"
+    assert c.scheduler_milestones == [1, 2]
+    assert c.gradient_clipping == 0.0  # Q11: the flag is parsed but never copied
+    back = TrainingConfig.from_json(c.to_json())
+    assert back.model_config == c.model_config and back.batch_size == 2
+    assert json.loads(c.to_json())["model_config"]["input_channels"] == 64
+    # dataclass defaults (config.py:11-94)
+    d = TrainingConfig()
+    assert (d.learning_rate, d.scheduler, d.n_epochs, d.checkpoint_every) == (1e-4, "OneCycleLR", 100, 25)
+
+
+def test_synthetic_batches_and_sharding():
+    ld = get_dataloader("synthetic://clips=10,frames=50,seed=3", input_channels=16, batch_size=4,
+                        use_video=False)
+    batches = list(ld)
+    assert len(ld) == 3 and len(batches) == 3
+    audio, video, contexts, fps, info = batches[0]
+    assert audio.shape == (4, 16, 50) and video is None and len(contexts) == 4
+    assert torch.equal(audio.sum(1), torch.ones(4, 50))
+    assert batches[-1].audio.shape[0] == 2
+    again = list(get_dataloader("synthetic://clips=10,frames=50,seed=3", 16, 4, use_video=False))
+    assert torch.equal(again[1].audio, batches[1].audio)
+    # two ranks see disjoint clips covering the set
+    seen = []
+    for r in range(2):
+        l = get_dataloader("synthetic://clips=10,frames=50,seed=3", 16, 5, use_video=False,
+                           rank=r, world_size=2)
+        seen.append({f for b in l for f in b.filepaths})
+    assert not (seen[0] & seen[1]) and len(seen[0] | seen[1]) == 10
+    crop = next(iter(get_dataloader("synthetic://clips=2,frames=100", 16, 2, use_video=False,
+                                    batch_subsample_frac=0.25)))
+    assert crop.audio.shape == (2, 16, 25)
+    with pytest.raises(NotImplementedError):
+        get_dataloader("synthetic://clips=2,frames=100", 16, 2, use_video=True)
+    with pytest.raises(ValueError):
+        get_dataloader("/data/kinetics", 16, 2, use_video=False)
+
+
+def test_mu_law_roundtrip_formula():
+    x = torch.linspace(-1, 1, 1001)
+    q = mu_law_encoding(x, 256)
+    assert q.min() == 0 and q.max() == 255 and torch.all(q[1:] >= q[:-1])
+    y = mu_law_decoding(q, 256)
+    assert (y - x).abs().max() < 0.03 and abs(float(mu_law_decoding(torch.tensor([128]), 256))) < 0.01
+
+
+def test_optimizer_and_scheduler_factories():
+    from movenet_amd.pytorch_lightning_trainer import Dance2Music
+    cfg = TrainingConfig(model_config=ModelConfig(2, 2, 16, 8, 8), batch_size=2, n_epochs=3,
+                         use_video=False, scheduler="OneCycleLR", accumulation_steps=2)
+    m = Dance2Music("synthetic://clips=8,frames=40", cfg)
+    o = m.configure_optimizers()
+    assert isinstance(o["optimizer"], torch.optim.AdamW)
+    sch = o["lr_scheduler"]["scheduler"]
+    assert isinstance(sch, torch.optim.lr_scheduler.OneCycleLR) and o["lr_scheduler"]["interval"] == "step"
+    assert sch.total_steps == 3 * 2  # epochs * ceil(4 batches / 2 accumulation)
+    for name, klass in (("SGD", torch.optim.SGD), ("RMSprop", torch.optim.RMSprop), ("Adam", torch.optim.Adam)):
+        cfg2 = TrainingConfig(model_config=ModelConfig(2, 2, 16, 8, 8), optimizer=name, scheduler="StepLR",
+                              use_video=False)
+        assert isinstance(Dance2Music("synthetic://clips=2,frames=40", cfg2).configure_optimizers()["optimizer"], klass)
+    with pytest.raises(ValueError, match="optimizer"):
+        Dance2Music("synthetic://clips=2,frames=40",
+                    TrainingConfig(optimizer="LBFGS", use_video=False)).configure_optimizers()
+    with pytest.raises(ValueError, match="scheduler"):
+        Dance2Music("synthetic://clips=2,frames=40",
+                    TrainingConfig(scheduler="Cosine", use_video=False)).configure_optimizers()
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank: int, world: int, port: int, out_dir: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from movenet_amd.parallel import FlatGradSync, init_distributed
+    r, w, _ = init_distributed("gloo", str(port))
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)  # different initial weights per rank on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3),
+                              torch.nn.Linear(3, 3))
+    for p in net[3].parameters():
+        p.requires_grad_(True)
+    sync = FlatGradSync(net.parameters(), w)
+    sync.broadcast_parameters(0)
+    torch.manual_seed(7 + rank)
+    x = torch.randn(4, 5)
+    net[2](net[1](net[0](x))).pow(2).sum().backward()  # net[3] unused: its grads stay None
+    local = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
+    sent = sync.sync_gradients()
+    torch.save({"params": [p.detach().clone() for p in net.parameters()], "local": local,
+                "synced": [p.grad for p in net.parameters()], "sent": sent},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"r{i}.pt", weights_only=True) for i in range(world)]
+    for a, b in zip(r[0]["params"], r[1]["params"]):
+        assert torch.equal(a, b)  # rank 0's weights everywhere
+    assert r[0]["sent"] == r[1]["sent"] == 5 * 7 + 7 + 7 * 3 + 3
+    for i, (g0, g1) in enumerate(zip(r[0]["synced"], r[1]["synced"])):
+        if g0 is None:
+            assert g1 is None and r[0]["local"][i] is None  # unused parameters are left alone
+            continue
+        assert torch.equal(g0, g1)
+        assert torch.allclose(g0, (r[0]["local"][i] + r[1]["local"][i]) / 2, atol=1e-6)
