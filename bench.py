@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--new-samples", type=int, default=16000, help="samples per sequence per step")
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream, 3 pipe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
     args = ap.parse_args()
@@ -242,6 +242,7 @@ def main():
         elapsed = float(t.item())
 
     assert gen.t == rf - 1 + (K + W) * n_new
+    gen.check_errors()
     variant_used = gen.variant
     total_samples = world * BATCH * n_new * K
     value = total_samples / elapsed
@@ -279,7 +280,7 @@ def main():
                 "batch_per_gpu": BATCH,
                 "new_samples_per_sequence_per_step": n_new,
                 "prompt": rf,
-                "kernel_variant": {1: "generic", 2: "stream64"}[variant_used],
+                "kernel_variant": {1: "generic", 2: "stream64", 3: "pipe64"}[variant_used],
                 "parallelism": f"independent clips x{world} (no collective)",
             },
             "samples_per_s_per_gpu": value / world,
@@ -293,7 +294,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
                 "traffic": None,
-                "kernel": "gen_stream64_kernel" if variant_used == 2 else "gen_generic_kernel",
+                "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe64_kernel"}[variant_used],
                 "flop_per_launch": flops_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,
                 "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",

@@ -90,17 +90,23 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
  * inputs it saw, one generated sample costs one pass over the weights.
  * ------------------------------------------------------------------------ */
 
-/* Kernel variants: GENERIC handles any dims (C,K <= 256, Q <= 1024, multiples
- * of 4); the STREAM variants are the tuned ones (one workgroup per sequence,
- * weights streamed from L2 through double-buffered registers).               */
+/* Kernel variants: GENERIC handles any dims (C,K <= 256, Q <= 1024); STREAM
+ * (C=K=64, Q=256) runs one workgroup per sequence and streams the weights from
+ * L2 through double-buffered registers; PIPE see below.                        */
 #define MVN_GEN_AUTO 0
 #define MVN_GEN_GENERIC 1
 #define MVN_GEN_STREAM 2
+#define MVN_GEN_PIPE 3 /* C=K=64, Q=256: layer pipeline over ceil(L/4)+1 CUs per
+                          sequence, weights resident in registers/LDS, activations
+                          handed on as sc1 granules; needs batch*stages <= #CUs   */
 
-/* Resolve MVN_GEN_AUTO for `dims`; returns the variant or a negative error. */
-int mvn_gen_variant(const mvn_dims *dims, int requested);
+/* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
+ * variant or a negative error.  The packed weight layout depends on the variant:
+ * pack and generate must be given the same resolved value. */
+int mvn_gen_variant(const mvn_dims *dims, int requested, int batch);
 
-/* Size in floats of the packed weight blob / of the ring-buffer state. */
+/* Size in floats of the packed weight blob / of the generator state (dilation
+ * queues, plus the PIPE variant's hand-off area when the dims allow PIPE). */
 size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant);
 size_t mvn_gen_state_floats(const mvn_dims *dims, int batch);
 

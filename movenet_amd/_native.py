@@ -19,7 +19,7 @@ MVN_ERR_TOO_SHORT = -3
 MVN_ERR_LAUNCH = -4
 MVN_ERR_UNSUPPORTED = -5
 
-GEN_AUTO, GEN_GENERIC, GEN_STREAM = 0, 1, 2
+GEN_AUTO, GEN_GENERIC, GEN_STREAM, GEN_PIPE = 0, 1, 2, 3
 
 
 class NativeLibraryError(RuntimeError):
@@ -82,7 +82,7 @@ SIGNATURES = {
     "mvn_last_error": (C.c_char_p, []),
     "mvn_receptive_fields": (C.c_int, [C.POINTER(Dims)]),
     "mvn_output_size": (C.c_int, [C.POINTER(Dims), C.c_int]),
-    "mvn_gen_variant": (C.c_int, [C.POINTER(Dims), C.c_int]),
+    "mvn_gen_variant": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_int]),
     "mvn_gen_weights_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_state_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_pack_weights": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(Params), C.c_void_p,

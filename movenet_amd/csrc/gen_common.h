@@ -1,0 +1,58 @@
+// Shared by the generator kernels (generate.hip, generate_pipe.hip).
+#pragma once
+#include "common.h"
+
+namespace mvn {
+
+struct GenArgs {
+  int L, layer_size, Q, C, K;
+  const float *w;
+  float *state;
+  long long state_per_seq;
+  int32_t *samples;
+  int stride, n_total, n_given, t_begin, t_end;
+  float temperature;
+  uint64_t seed;
+  float *logits_out;
+  int32_t *choices_out;
+  int logits_t0;
+};
+
+__device__ __forceinline__ int ring_offset(int l, int layer_size, int C) {
+  const int stack = l / layer_size, pos = l - stack * layer_size;
+  return C * (stack * ((1 << layer_size) - 1) + ((1 << pos) - 1));
+}
+
+// LDS-only barrier: outstanding global loads (the weight prefetch) stay in
+// flight across it.  __syncthreads() would add a full vmcnt(0) drain whenever a
+// global store is pending.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float ring_load(const float *p) {
+  // agent-scope relaxed load: served by L2, never by a stale L1 line
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// full f/g matrix element: row o in [0,2C) (filter | gate), column k in [0,2C)
+// (tap 0 = past | tap 1 = current)
+__device__ __forceinline__ float fg_elem(const float *fw, const float *gw, int C, int o, int k) {
+  const int tap = k >= C, kc = k - tap * C;
+  const float *w = o < C ? fw : gw;
+  const int oc = o < C ? o : o - C;
+  return w[((size_t)oc * C + kc) * 2 + tap];
+}
+__device__ __forceinline__ float rs_elem(const float *rw, const float *sw, int C, int o, int k) {
+  return o < C ? rw[(size_t)o * C + k] : sw[(size_t)(o - C) * C + k];
+}
+
+
+// ---- PIPE variant (generate_pipe.hip) ------------------------------------
+bool pipe_ok(const mvn_dims *d);
+int pipe_stages(const mvn_dims *d);
+size_t pipe_hand_floats(const mvn_dims *d, int batch);  // hand-off area appended to the state
+int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);
+int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s);
+
+}  // namespace mvn

@@ -24,39 +24,9 @@
 //            buffers (one block of <=16 float4 per thread always in flight),
 //            embedding tables resident in LDS, activations exchanged in LDS.
 #include "common.h"
+#include "gen_common.h"
 
 namespace mvn {
-
-struct GenArgs {
-  int L, layer_size, Q, C, K;
-  const float *w;
-  float *state;
-  long long state_per_seq;
-  int32_t *samples;
-  int stride, n_total, n_given, t_begin, t_end;
-  float temperature;
-  uint64_t seed;
-  float *logits_out;
-  int32_t *choices_out;
-  int logits_t0;
-};
-
-__device__ __forceinline__ int ring_offset(int l, int layer_size, int C) {
-  const int stack = l / layer_size, pos = l - stack * layer_size;
-  return C * (stack * ((1 << layer_size) - 1) + ((1 << pos) - 1));
-}
-
-// LDS-only barrier: outstanding global loads (the weight prefetch) stay in
-// flight across it.  __syncthreads() would add a full vmcnt(0) drain whenever a
-// global store is pending.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ float ring_load(const float *p) {
-  // agent-scope relaxed load: served by L2, never by a stale L1 line
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ======================================================================
 // GENERIC variant
@@ -565,18 +535,6 @@ __global__ void pack_embed_kernel(const float *__restrict__ causal_w, float *__r
   dst[i] = causal_w[((size_t)c * Q + q) * 2 + tap];
 }
 
-// full f/g matrix element: row o in [0,2C) (filter | gate), column k in [0,2C)
-// (tap 0 = past | tap 1 = current)
-__device__ __forceinline__ float fg_elem(const float *fw, const float *gw, int C, int o, int k) {
-  const int tap = k >= C, kc = k - tap * C;
-  const float *w = o < C ? fw : gw;
-  const int oc = o < C ? o : o - C;
-  return w[((size_t)oc * C + kc) * 2 + tap];
-}
-__device__ __forceinline__ float rs_elem(const float *rw, const float *sw, int C, int o, int k) {
-  return o < C ? rw[(size_t)o * C + k] : sw[(size_t)(o - C) * C + k];
-}
-
 __global__ void pack_layer_generic_kernel(const float *fw, const float *gw, const float *rw,
                                           const float *rb, const float *sw, const float *sb,
                                           float *__restrict__ dst, int C, int K) {
@@ -667,10 +625,30 @@ static bool stream_ok(const mvn_dims *d) {
 
 extern "C" {
 
-int mvn_gen_variant(const mvn_dims *dims, int requested) {
+static int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 256;  // no device visible (build box): the MI355X figure
+  return cus;
+}
+
+int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   int rc = mvn::validate_dims(dims);
   if (rc) return rc;
-  if (requested == MVN_GEN_AUTO) return mvn::stream_ok(dims) ? MVN_GEN_STREAM : MVN_GEN_GENERIC;
+  const bool pipe_fits =
+      mvn::pipe_ok(dims) && batch >= 1 && batch * mvn::pipe_stages(dims) <= device_cus();
+  if (requested == MVN_GEN_AUTO) {
+    if (pipe_fits) return MVN_GEN_PIPE;
+    return mvn::stream_ok(dims) ? MVN_GEN_STREAM : MVN_GEN_GENERIC;
+  }
+  if (requested == MVN_GEN_PIPE) {
+    if (!pipe_fits) {
+      mvn::set_error("PIPE variant needs C=K=64, Q=256 and batch*(ceil(L/4)+1) <= number of CUs");
+      return MVN_ERR_UNSUPPORTED;
+    }
+    return MVN_GEN_PIPE;
+  }
   if (requested == MVN_GEN_STREAM) {
     if (!mvn::stream_ok(dims)) {
       mvn::set_error("STREAM variant needs C=K=64, Q=256, <=80 layers");
@@ -691,23 +669,30 @@ int mvn_gen_variant(const mvn_dims *dims, int requested) {
 }
 
 size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant) {
-  variant = mvn_gen_variant(dims, variant);
+  variant = mvn_gen_variant(dims, variant, 1);
   if (variant < 0) return 0;
   const size_t C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const size_t L = mvn::n_layers(dims);
-  if (variant == MVN_GEN_STREAM)
+  if (variant == MVN_GEN_STREAM || variant == MVN_GEN_PIPE)
     return mvn::s64::EMB_FLOATS + 4 * (L * mvn::s64::LAYER_F4 + mvn::s64::HEAD_F4);
   return 2 * Q * C + L * (4 * C * C + C * (C + K) + (C + K)) + K * Q + Q + Q * Q + Q;
 }
 
 size_t mvn_gen_state_floats(const mvn_dims *dims, int batch) {
   if (mvn::validate_dims(dims) || batch < 0) return 0;
-  return (size_t)batch * (size_t)mvn::dilation_sum(dims) * dims->residual_channels;
+  // dilation queues, then (C=K=64, Q=256 only) the PIPE variant's hand-off area
+  size_t n = (size_t)batch * (size_t)mvn::dilation_sum(dims) * dims->residual_channels;
+  if (mvn::pipe_ok(dims)) n += mvn::pipe_hand_floats(dims, batch);
+  return n;
 }
 
 int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p, float *packed,
                          void *stream_) {
-  variant = mvn_gen_variant(dims, variant);
+  if (variant == MVN_GEN_AUTO) {
+    mvn::set_error("mvn_gen_pack_weights: resolve the variant with mvn_gen_variant first");
+    return MVN_ERR_BAD_ARG;
+  }
+  variant = mvn_gen_variant(dims, variant, 1);
   if (variant < 0) return variant;
   if (!p || !packed || !p->causal_w || !p->filter_w || !p->gate_w || !p->residual_w ||
       !p->residual_b || !p->skip_w || !p->skip_b || !p->head1_w || !p->head1_b || !p->head2_w ||
@@ -716,6 +701,7 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
     return MVN_ERR_BAD_ARG;
   }
   hipStream_t stream = (hipStream_t)stream_;
+  if (variant == MVN_GEN_PIPE) return mvn::pipe_pack(dims, p, packed, stream);
   const int C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const int L = mvn::n_layers(dims);
   {
@@ -750,7 +736,12 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
                  int32_t *samples, int batch, int sample_stride, int n_total, int n_given,
                  int t_begin, int t_end, float temperature, uint64_t seed, float *logits_out,
                  int32_t *choices_out, int logits_t0, void *stream) {
-  variant = mvn_gen_variant(dims, variant);
+  if (variant == MVN_GEN_AUTO) {
+    mvn::set_error("mvn_generate: resolve the variant with mvn_gen_variant first (the packed "
+                   "weight layout depends on it)");
+    return MVN_ERR_BAD_ARG;
+  }
+  variant = mvn_gen_variant(dims, variant, batch > 0 ? batch : 1);
   if (variant < 0) return variant;
   if (!packed || !state || !samples || batch < 0 || n_total < 1 || sample_stride < n_total ||
       n_given < 1 || n_given > n_total || t_begin < 0 || t_end < t_begin || t_end > n_total ||
@@ -781,6 +772,10 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
   a.logits_out = logits_out;
   a.choices_out = choices_out;
   a.logits_t0 = logits_t0;
+  if (variant == MVN_GEN_PIPE) {
+    float *hand = state + (size_t)batch * a.state_per_seq;
+    return mvn::pipe_launch(a, dims, batch, hand, (hipStream_t)stream);
+  }
   if (variant == MVN_GEN_STREAM) {
     const size_t lds =
         sizeof(float) * ((size_t)mvn::s64::EMB_FLOATS + 128 + 256 + 64 + 256 + 64 + 256 + 32 + 8 +

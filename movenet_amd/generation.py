@@ -89,12 +89,15 @@ class RingGenerator:
         self.n_layers = layer_size * stack_size
         self.Q = input_channels
         self.rf = N.check(self.lib.mvn_receptive_fields(self.dims), "mvn_receptive_fields")
-        self.variant = N.check(self.lib.mvn_gen_variant(self.dims, variant), "mvn_gen_variant")
         self.batch, self.n_total = int(batch), int(n_total)
+        with torch.cuda.device(self.device):
+            self.variant = N.check(self.lib.mvn_gen_variant(self.dims, variant, self.batch),
+                                   "mvn_gen_variant")
         self.temperature, self.seed = float(temperature), int(seed) & (2 ** 64 - 1)
         with torch.cuda.device(self.device):
             nw = self.lib.mvn_gen_weights_floats(self.dims, self.variant)
             ns = self.lib.mvn_gen_state_floats(self.dims, self.batch)
+            self._queue_floats = self.batch * (self.rf - stack_size) * residual_channels
             self.packed = torch.empty(nw, dtype=torch.float32, device=self.device)
             self.state = torch.zeros(max(ns, 1), dtype=torch.float32, device=self.device)
             self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
@@ -117,6 +120,15 @@ class RingGenerator:
     def reset(self) -> None:
         self.state.zero_()
         self.t = 0
+
+    def check_errors(self) -> None:
+        """Synchronise and raise if a PIPE hand-off timed out (workgroups of a
+        pipeline not co-resident, e.g. another kernel occupying the CUs)."""
+        torch.cuda.current_stream(self.device).synchronize()
+        if self.variant == N.GEN_PIPE:
+            flags = self.state[-64:]
+            if int(flags.view(torch.int32)[0].item()) != 0:
+                raise RuntimeError("movenet_amd: PIPE generator hand-off timed out")
 
     def _run(self, t_begin: int, t_end: int, n_given: int, logits_out=None, choices_out=None,
              logits_t0: int = 0) -> None:

@@ -44,22 +44,29 @@ def test_receptive_fields_and_output_size():
 def test_generate_sizes_and_variants():
     lib = N.lib()
     d2 = N.make_dims(10, 3, 256, 64, 64)
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO) == N.GEN_STREAM
+    # 16 sequences x 9 pipeline stages fit the 256 CUs; 64 sequences do not
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 64) == N.GEN_STREAM
+    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 64) == N.MVN_ERR_UNSUPPORTED
     d1 = N.make_dims(2, 2, 64, 16, 16)
-    assert lib.mvn_gen_variant(d1, N.GEN_AUTO) == N.GEN_GENERIC
-    assert lib.mvn_gen_variant(d1, N.GEN_STREAM) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d1, N.GEN_AUTO, 2) == N.GEN_GENERIC
+    assert lib.mvn_gen_variant(d1, N.GEN_STREAM, 2) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d1, N.GEN_PIPE, 2) == N.MVN_ERR_UNSUPPORTED
     # audio-path parameters of the 30-layer model
     assert lib.mvn_gen_weights_floats(d2, N.GEN_GENERIC) == 856320
     assert lib.mvn_gen_weights_floats(d2, N.GEN_STREAM) == 856320
-    # dilation queues: D*C floats per sequence (786 KB fp32)
-    assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64
-    assert lib.mvn_gen_state_floats(d2, 16) == 16 * 3069 * 64
+    assert lib.mvn_gen_weights_floats(d2, N.GEN_PIPE) == 856320
+    # dilation queues: D*C floats per sequence (786 KB fp32) + the PIPE
+    # variant's hand-off area (9 stages x 128 eight-byte granules per sequence + flags)
+    assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 9 * 256 + 64
+    assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 9 * 256) + 64
+    assert lib.mvn_gen_state_floats(d1, 2) == 2 * 6 * 16
 
 
 def test_bad_arguments_are_refused_before_any_launch():
     lib = N.lib()
     d2 = N.make_dims(10, 3, 256, 64, 64)
-    rc = lib.mvn_generate(d2, 0, None, None, None, 1, 10, 10, 1, 0, 5, 0.0, 0, None, None, 0, None)
+    rc = lib.mvn_generate(d2, N.GEN_STREAM, None, None, None, 1, 10, 10, 1, 0, 5, 0.0, 0, None, None, 0, None)
     assert rc == N.MVN_ERR_BAD_ARG
     with pytest.raises(ValueError):
         N.check(rc, "mvn_generate")

@@ -27,7 +27,7 @@ def _variants(cfg):
     from movenet_amd import _native as N
     out = [N.GEN_GENERIC]
     if cfg["residual_channels"] == 64 and cfg["skip_channels"] == 64 and cfg["input_channels"] == 256:
-        out.append(N.GEN_STREAM)
+        out += [N.GEN_STREAM, N.GEN_PIPE]
     return out
 
 
@@ -43,15 +43,17 @@ def test_small_teacher_forced_logits(golden):
     assert np.array_equal(choices[:, rf:].cpu().numpy(), want.argmax(2))
 
 
-@pytest.mark.parametrize("which", ["generic", "stream"])
+@pytest.mark.parametrize("which", ["generic", "stream", "pipe"])
 def test_l30_teacher_forced_logits(golden, which):
     from movenet_amd import _native as N
     fx = golden("g2_l30_forward.npz")
     cfg, dims, sd = weights_of(fx)
     B, T, rf = int(fx["B"]), int(fx["T"]), dims.receptive_fields
     idx = synthetic_indices(B, T, 256, int(fx["idx_seed"]))
-    g = _gen(cfg, sd, B, T, variant=N.GEN_GENERIC if which == "generic" else N.GEN_STREAM)
+    g = _gen(cfg, sd, B, T, variant={"generic": N.GEN_GENERIC, "stream": N.GEN_STREAM,
+                                     "pipe": N.GEN_PIPE}[which])
     choices, logits = g.teacher_forced(idx.to(DEV), logits_t0=rf)
+    g.check_errors()
     want = np.transpose(fx["logits"][:, :, :-1], (0, 2, 1))
     assert rel_err(logits.cpu().numpy(), want) < LOGIT_TOL
 
@@ -66,7 +68,15 @@ def test_greedy_free_running_indices_bit_exact(golden, name):
         g = _gen(cfg, sd, B, N_, variant=variant)
         g.prime(pidx.to(DEV))
         g.advance(N_ - rf)
+        g.check_errors()
         assert np.array_equal(g.samples.cpu().numpy(), fx["indices"]), f"variant {variant}"
+        # queues primed by stepping (not by the forward kernels) give the same run
+        g1 = _gen(cfg, sd, B, N_, variant=variant)
+        g1.prime_with_forward = False
+        g1.prime(pidx.to(DEV))
+        g1.advance(N_ - rf)
+        g1.check_errors()
+        assert np.array_equal(g1.samples.cpu().numpy(), fx["indices"]), f"variant {variant} (stepped)"
         # chunked launches carry the queues across calls
         g2 = _gen(cfg, sd, B, N_, variant=variant)
         g2.prime(pidx.to(DEV))
@@ -130,12 +140,14 @@ def test_config2_full_size_properties():
     rf, B, n_new = 3072, 16, 96
     pidx = synthetic_indices(B, rf, 256, 1234).to(DEV)
     runs = {}
-    for variant in (N.GEN_GENERIC, N.GEN_STREAM):
+    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_PIPE):
         g = _gen(cfg, sd, B, rf + n_new, variant=variant)
         g.prime(pidx)
         g.advance(n_new)
+        g.check_errors()
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_GENERIC], runs[N.GEN_STREAM])
+    assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
     g = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_STREAM)
     choices, logits = g.teacher_forced(runs[N.GEN_STREAM], logits_t0=rf)
     assert torch.equal(choices[:, rf:], runs[N.GEN_STREAM][:, rf:])
