@@ -10,7 +10,10 @@ import ctypes as C
 import os
 from typing import Optional, Sequence
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmovenet_hip.so")
+# MOVENET_HIP_LIB selects another build of the SAME library (the diagnostic twin with
+# in-kernel stamps); it is not a fallback mechanism.
+LIB_PATH = os.environ.get("MOVENET_HIP_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "lib", "libmovenet_hip.so")
 
 MVN_OK = 0
 MVN_ERR_BAD_DIMS = -1

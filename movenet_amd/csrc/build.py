@@ -48,6 +48,23 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def build_stamps(verbose: bool = True, exp: int = 0) -> str:
+    """Diagnostic twin of the library with in-kernel wall-clock stamps in the PIPE
+    generator (never loaded by the product; see scripts/pipe_stamps.py)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    out = os.path.join(LIB_DIR, "libmovenet_hip_stamps.so" if exp == 0 else f"libmovenet_hip_exp{exp}.so")
+    cmd = [_hipcc()] + FLAGS + ["-DMVN_PIPE_STAMPS", f"-DMVN_EXP={exp}",
+                                "-I", os.path.join(ROOT, "include"), "-I", HERE]
+    cmd += _source_paths() + ["-o", out]
+    if verbose:
+        print("[movenet_amd] " + " ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, cwd=LIB_DIR, capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout + proc.stderr)
+        raise RuntimeError("hipcc failed building libmovenet_hip_stamps.so")
+    return out
+
+
 def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     digest = _digest()
@@ -76,5 +93,10 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -
 
 
 if __name__ == "__main__":
+    if "--stamps" in sys.argv:
+        exps = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--exp=")] or [0]
+        for e in exps:
+            print(build_stamps(verbose=False, exp=e))
+        sys.exit(0)
     path = build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv)
     print(path)

@@ -3,8 +3,9 @@
 // The STREAM variant re-reads 3.3 MB of weights from L2 for every generated
 // sample (one CU per sequence, ~42 GB/s => 78 us per step).  Here each sequence
 // gets a private pipeline of NS = ceil(L/4)+1 workgroups (512 threads, one per
-// CU): stage s keeps the weights of layers 4s..4s+3 in registers (current-tap
-// and residual/skip matrices, 128 VGPRs per thread) and LDS (past-tap matrix),
+// CU): stage s keeps the weights of layers 4s..4s+3 in registers (waves 0-3 the
+// current-tap filter|gate matrices, waves 4-7 the residual|skip matrices, 128
+// VGPRs per thread) and LDS (past-tap matrix),
 // the last stage keeps the dense head in registers and the embedding tables in
 // LDS.  Nothing is re-read per step; what moves is the activation: 64 residual
 // + 64 skip-sum floats travel from stage to stage as 128 eight-byte
@@ -35,9 +36,33 @@ constexpr int EMB_F = 2 * Q * C;
 constexpr int W1_F = Q * C, W2_F = Q * Q;
 constexpr int HEAD_F = W1_F + Q + W2_F + Q;
 constexpr int GRAN = 128;                    // granules per inbox
-constexpr int LDS_FLOATS = 33280;            // max(layer stage, head stage), see kernel
+constexpr int LDS_FLOATS = 33408;            // max(layer stage, head stage) + 16 flag words
 constexpr unsigned SPIN_LIMIT = 1u << 23;
 }  // namespace p64
+
+#ifdef MVN_PIPE_STAMPS
+// Diagnostic build only (python -m movenet_amd.csrc.build --stamps): wall-clock
+// (s_memrealtime, 100 MHz) stamps of "inbox complete" and "outbox sent" per stage
+// for the first 64 steps of a launch; read back with mvn_debug_read_stamps().
+__device__ unsigned long long g_stamps[16][16][64][4];
+#define MVN_STAMP(bb, ss, step, which)                                              \
+  do {                                                                              \
+    if ((bb) < 16 && (ss) < 16 && (step) < 64 && threadIdx.x == 0) {                \
+      g_stamps[bb][ss][step][which] = __builtin_amdgcn_s_memrealtime();             \
+      g_stamps[bb][ss][step][2 + (which)] = __builtin_amdgcn_s_memtime();           \
+    }                                                                               \
+  } while (0)
+// finer shader-clock stamps inside the first layer of a stage (thread `who`)
+__device__ unsigned long long g_fine[16][16][64][8];
+#define MVN_FINE(bb, ss, step, slot, who)                                           \
+  do {                                                                              \
+    if ((bb) < 16 && (ss) < 16 && (step) < 64 && threadIdx.x == (who))              \
+      g_fine[bb][ss][step][slot] = __builtin_amdgcn_s_memtime();                    \
+  } while (0)
+#else
+#define MVN_STAMP(bb, ss, step, which) do {} while (0)
+#define MVN_FINE(bb, ss, step, slot, who) do {} while (0)
+#endif
 
 __device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v) {
   __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -69,24 +94,103 @@ __device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsign
   }
 }
 
-__device__ __forceinline__ float dot16(const float (&w)[16], const float *x) {
-  const f4 *x4 = (const f4 *)x;
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i += 2) {
-    const f4 xa = x4[i], xb = x4[i + 1];
-    a0 = fmaf(w[4 * i + 0], xa.x, a0);
-    a0 = fmaf(w[4 * i + 1], xa.y, a0);
-    a0 = fmaf(w[4 * i + 2], xa.z, a0);
-    a0 = fmaf(w[4 * i + 3], xa.w, a0);
-    a1 = fmaf(w[4 * i + 4], xb.x, a1);
-    a1 = fmaf(w[4 * i + 5], xb.y, a1);
-    a1 = fmaf(w[4 * i + 6], xb.z, a1);
-    a1 = fmaf(w[4 * i + 7], xb.w, a1);
-  }
-  return a0 + a1;
+// ---- cross-lane moves as DPP (one VALU op) instead of ds_bpermute (an LDS round trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each group of 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each row of 16
+
+// sum over each aligned group of 4 lanes, result in all 4
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_mov<DPP_XOR1>(v);
+  v += dpp_mov<DPP_XOR2>(v);
+  return v;
+}
+// after quad_sum: the value held by the OTHER quad of the same group of 8
+__device__ __forceinline__ float other_quad(float v) { return dpp_mov<DPP_HALF_MIRROR>(v); }
+
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = quad_sum(v);
+  v += dpp_mov<DPP_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_MIRROR>(v);  // every lane of a row of 16 now holds the row sum
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+// tanh(f) * sigmoid(g) from two v_exp_f32 and one reciprocal-based division:
+//   tanh(f) = (1 - e^-2|f|) / (1 + e^-2|f|) * sign(f),  sigmoid(g) = 1 / (1 + e^-g)
+// Absolute error ~1e-7 (fp32 rounding of an O(1) value); ~12 VALU ops vs ~100 for
+// the libm forms, and this sits on the per-layer critical path.
+__device__ __forceinline__ float gate_fast(float f, float g) {
+  const float a = __expf(-2.0f * fabsf(f));       // in (0, 1]
+  const float e = __expf(-g);                      // may overflow to +inf: 1/inf = 0 is right
+  const float num = copysignf(1.0f - a, f);
+  const float den = (1.0f + a) * (1.0f + e);
+  return num * __builtin_amdgcn_rcpf(den);  // v_rcp_f32: 1 ulp
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef MVN_EXP
+#define MVN_EXP 0   // timing experiments of scripts/pipe_stamps.py; 0 = the product
+#endif
+
+// 32-term dot product as 16 packed FMAs (v_pk_fma_f32): w and x as 16 float2;
+// two interleaved partial sums (even / odd terms), fixed order.
+__device__ __forceinline__ float dot32(const v2f (&w)[16], const float *x) {
+  // four independent accumulation chains (the packed FMA has ~8 cycles of dependent
+  // latency: one chain of 16 would serialise), combined in a fixed order
+  const f4 *x4 = (const f4 *)x;
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const f4 xv = x4[i], yv = x4[i + 1];
+    a0 = __builtin_elementwise_fma(w[2 * i], v2f{xv.x, xv.y}, a0);
+    a1 = __builtin_elementwise_fma(w[2 * i + 1], v2f{xv.z, xv.w}, a1);
+    a2 = __builtin_elementwise_fma(w[2 * i + 2], v2f{yv.x, yv.y}, a2);
+    a3 = __builtin_elementwise_fma(w[2 * i + 3], v2f{yv.z, yv.w}, a3);
+  }
+  const v2f t = (a0 + a1) + (a2 + a3);
+  return t.x + t.y;
+}
+__device__ __forceinline__ void load32(v2f (&w)[16], const f4 *src, int stride, int idx) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f4 v = src[i * stride + idx];
+    w[2 * i] = v2f{v.x, v.y};
+    w[2 * i + 1] = v2f{v.z, v.w};
+  }
+}
+
+// (value, index) arg-max combine: larger value wins, smaller index on ties
+__device__ __forceinline__ void argmax_take(float &bv, int &bi, float ov, int oi) {
+  if (ov > bv || (ov == bv && oi < bi)) {
+    bv = ov;
+    bi = oi;
+  }
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// Workgroup = 8 waves.  Waves 0-3 ("FG group") own the filter/gate matrices, waves
+// 4-7 ("RS group") the residual/skip matrices: at any moment ONE wave per SIMD is
+// issuing, so the dependent chain is not slowed by a co-resident wave replaying the
+// same bookkeeping instructions, and each thread keeps 4 layers x 32 weights = 128
+// VGPRs resident.
 __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand, unsigned *err,
                                                            int NS) {
   using namespace p64;
@@ -101,45 +205,47 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
   if (s < NS - 1) {
     // ================= layer stage: layers l0 .. l0+nl-1 =================
     const int l0 = s * LPS, nl = min(LPS, L - l0);
-    const int q = tid & 3;
-    const int fc = tid >> 3, which = (tid >> 2) & 1;  // f/g mapping: channel, f|g, k-quarter
-    const int o = tid >> 2;                           // r/s mapping: row (res 0..63 | skip 64..127)
-    float *wp = smem;                  // [LPS][4][512] float4: past-tap f|g weights
-    float *cur = smem + LPS * MAT_F;   // [64]
-    float *zb = cur + 64;              // [64]
-    float *pastb = zb + 64;            // [LPS][64]
+    const bool fg_group = tid < 256;
+    const int t = tid & 255, h = t & 1;
+    const int fc = t >> 2, which = (t >> 1) & 1;  // FG: channel, f|g       (k half = h)
+    const int o = t >> 1;                          // RS: row res 0..63 | skip 64..127
+    float *wp = smem;                  // [LPS][8][256] float4: past-tap f|g weights (FG group)
+    float *cur = smem + LPS * MAT_F;   // [64] residual stream
+    float *zb = cur + 64;              // [64] gated activation
+    float *pastb = zb + 64;            // [LPS][64] popped queue entries
     float *skin = pastb + LPS * 64;    // [64] running skip sum as received
     float *ring = a.state + (size_t)b * a.state_per_seq;
 
-    float wc[LPS][16], wr[LPS][16], bias[LPS], pj[LPS], xs[LPS];
+    v2f w[LPS][16];                    // FG group: current-tap f|g rows; RS group: res|skip rows
+    float bias[LPS], pj[LPS], xs[LPS];
     int doff[LPS], dmask[LPS];
 #pragma unroll
     for (int j = 0; j < LPS; ++j) {
       bias[j] = 0.f; pj[j] = 0.f; xs[j] = 0.f; doff[j] = 0; dmask[j] = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { wc[j][i] = 0.f; wr[j][i] = 0.f; }
+      for (int i = 0; i < 16; ++i) w[j][i] = v2f{0.f, 0.f};
       if (j < nl) {
         const float *lw = a.w + EMB_F + (size_t)(l0 + j) * LAYER_F;
-        const f4 *wc4 = (const f4 *)lw, *wp4 = (const f4 *)(lw + MAT_F),
-                 *wr4 = (const f4 *)(lw + 2 * MAT_F);
+        if (fg_group) {
+          load32(w[j], (const f4 *)lw, 256, t);
+          const f4 *wp4 = (const f4 *)(lw + MAT_F);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f4 vc = wc4[i * NT + tid], vr = wr4[i * NT + tid];
-          wc[j][4 * i] = vc.x; wc[j][4 * i + 1] = vc.y; wc[j][4 * i + 2] = vc.z; wc[j][4 * i + 3] = vc.w;
-          wr[j][4 * i] = vr.x; wr[j][4 * i + 1] = vr.y; wr[j][4 * i + 2] = vr.z; wr[j][4 * i + 3] = vr.w;
-          ((f4 *)wp)[(j * 4 + i) * NT + tid] = wp4[i * NT + tid];
+          for (int i = 0; i < 8; ++i) ((f4 *)wp)[(j * 8 + i) * 256 + t] = wp4[i * 256 + t];
+        } else {
+          load32(w[j], (const f4 *)(lw + 2 * MAT_F), 256, t);
+          bias[j] = lw[3 * MAT_F + o];
         }
-        bias[j] = lw[3 * MAT_F + o];
         const int l = l0 + j;
         dmask[j] = (1 << (l % a.layer_size)) - 1;
         doff[j] = ring_offset(l, a.layer_size, C);
       }
     }
 
-    // queue pop for step tn (+ push of this step's inputs) and the past-tap half
-    // of the f/g pre-activations; runs while the other stages work
+    // Off the critical path: push this step's layer inputs into the dilation queues,
+    // pop the entries step tn needs (RS lanes), then the past-tap half of step tn's
+    // f/g pre-activations (FG group).
     auto precompute = [&](int tn, bool push) {
-      if (q == 0 && o < 64) {
+      if (!fg_group && h == 0 && o < 64) {
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
           if (j < nl) {
@@ -150,26 +256,23 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
           }
       }
       __syncthreads();
+      if (fg_group) {
 #pragma unroll
-      for (int j = 0; j < LPS; ++j)
-        if (j < nl) {
-          float w[16];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f4 v = ((const f4 *)wp)[(j * 4 + i) * NT + tid];
-            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) {
+            v2f wq[16];
+            load32(wq, (const f4 *)wp + j * 8 * 256, 256, t);
+            float p = dot32(wq, pastb + j * 64 + 32 * h);
+            p += dpp_mov<DPP_XOR1>(p);
+            pj[j] = p;
           }
-          float p = dot16(w, pastb + j * 64 + 16 * q);
-          p += __shfl_xor(p, 1, 64);
-          p += __shfl_xor(p, 2, 64);
-          pj[j] = p;
-        }
+      }
     };
     __syncthreads();
     precompute(a.t_begin, false);
 
-    for (int t = a.t_begin; t < a.t_end; ++t) {
-      const unsigned epoch = (unsigned)(t - a.t_begin + 1);
+    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       if (wave == 0) {
         float v0, v1;
         const bool ok = wait_inbox(inbox, epoch, err, v0, v1);
@@ -183,45 +286,71 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       }
       lds_barrier();
       if (iflag[0] == 0) break;
-      float skipacc = (q == 0 && o >= 64) ? skin[o - 64] : 0.f;
-      float outv = 0.f;
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
+      float skipacc = (!fg_group && h == 0 && o >= 64) ? skin[o - 64] : 0.f;
 #pragma unroll
       for (int j = 0; j < LPS; ++j)
         if (j < nl) {
-          // f,g: current-tap product + precomputed past-tap half
-          float p = dot16(wc[j], cur + 16 * q);
-          p += __shfl_xor(p, 1, 64);
-          p += __shfl_xor(p, 2, 64);
-          p += pj[j];
-          const float other = __shfl_xor(p, 4, 64);
-          const float z = gate(which ? other : p, which ? p : other);
-          if ((tid & 7) == 0) zb[fc] = z;
-          lds_barrier();
-          float r = dot16(wr[j], zb + 16 * q);
-          r += __shfl_xor(r, 1, 64);
-          r += __shfl_xor(r, 2, 64);
-          if (q == 0) {
-            const float v = r + bias[j];
-            if (o < 64) {
-              const float old = cur[o];
-              xs[j] = old;
-              outv = v + old;
-              cur[o] = outv;
-            } else {
-              skipacc += v;
-            }
-            // the stage's last layer: hand the activation on before anything else
-            if (j == nl - 1) put_granule(outbox + o, epoch, o < 64 ? outv : skipacc);
+          float old = 0.f;
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 0, 0);
+          if (fg_group) {
+            // f|g row: current-tap product over this lane's 32 inputs + other half + past half
+#if MVN_EXP == 3
+            float p = cur[32 * h] * w[j][0].x;
+#else
+            float p = dot32(w[j], cur + 32 * h);
+#endif
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 1, 0);
+            p += dpp_mov<DPP_XOR1>(p);
+            p += pj[j];
+            const float g = dpp_mov<DPP_XOR2>(p);  // f lanes (which == 0) receive g
+#if MVN_EXP == 1
+            const float z = p + g;
+#else
+            const float z = gate_fast(p, g);
+#endif
+            if ((t & 3) == 0) zb[fc] = z;
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 0);
+          } else if (h == 0 && o < 64) {
+            old = cur[o];  // this layer's input: residual add below, queue push later
           }
           lds_barrier();
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 256);
+          if (!fg_group) {
+#if MVN_EXP == 3
+            float r = zb[32 * h] * w[j][0].x;
+#else
+            float r = dot32(w[j], zb + 32 * h);
+#endif
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 4, 256);
+            r += dpp_mov<DPP_XOR1>(r);
+            if (h == 0) {
+              const float v = r + bias[j];
+              float outv;
+              if (o < 64) {
+                xs[j] = old;
+                outv = v + old;
+                cur[o] = outv;
+              } else {
+                skipacc += v;
+                outv = skipacc;
+              }
+              // the stage's last layer: hand the activation on before anything else
+              if (j == nl - 1) put_granule(outbox + o, epoch, outv);
+            }
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 5, 256);
+          }
+          lds_barrier();
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 6, 0);
         }
-      if (t + 1 < a.t_end) {
-        precompute(t + 1, true);
-      } else if (q == 0 && o < 64) {
+      MVN_STAMP(b, s, ts - a.t_begin, 1);
+      if (ts + 1 < a.t_end) {
+        precompute(ts + 1, true);
+      } else if (!fg_group && h == 0 && o < 64) {
         // last step of the launch: push only (the next launch pops in its prologue)
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
-          if (j < nl) ring[doff[j] + o + (t & dmask[j]) * C] = xs[j];
+          if (j < nl) ring[doff[j] + o + (ts & dmask[j]) * C] = xs[j];
       }
     }
     return;
@@ -232,8 +361,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     float *E0 = smem, *E1 = smem + Q * C;   // [Q][C] each
     float *a0 = smem + EMB_F;                // [64]
     float *a1 = a0 + 64;                     // [256]
-    float *red = a1 + 256;                   // [64]
-    int *ired = (int *)(red + 64);           // [16]
+    float *lgb = a1 + 256;                   // [256] logits
     const float *hw = a.w + EMB_F + (size_t)L * LAYER_F;
     const f4 *W1p = (const f4 *)hw, *W2p = (const f4 *)(hw + W1_F + Q);
     const float *b1 = hw + W1_F, *b2 = hw + W1_F + Q + W2_F;
@@ -247,32 +375,23 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     // conv1: thread (o1 = tid>>1, q1 = tid&1), 32 inputs; conv2: thread (og = tid>>3, q2 = tid&7),
     // 4 outputs x 32 inputs
     const int o1 = tid >> 1, q1 = tid & 1, og = tid >> 3, q2 = tid & 7;
-    float w1[32], w2[4][32];
+    v2f w1[16], w2[4][16];
+    load32(w1, W1p, NT, tid);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const f4 v = W1p[i * NT + tid];
-      w1[4 * i] = v.x; w1[4 * i + 1] = v.y; w1[4 * i + 2] = v.z; w1[4 * i + 3] = v.w;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f4 v = W2p[(r * 8 + i) * NT + tid];
-        w2[r][4 * i] = v.x; w2[r][4 * i + 1] = v.y; w2[r][4 * i + 2] = v.z; w2[r][4 * i + 3] = v.w;
-      }
+    for (int r = 0; r < 4; ++r) load32(w2[r], W2p + r * 8 * NT, NT, tid);
     const float b1r = b1[o1];
-    const int cls = 4 * og + (q2 & 3);
-    const bool active = q2 < 4;
-    const float b2r = b2[cls];
+    const float b2r = b2[4 * og + (q2 & 3)];
+    f4 b2l = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) b2l = ((const f4 *)b2)[lane];
     if (tid == 0) {
       iflag[1] = samples[a.t_begin];
       iflag[2] = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
     }
     __syncthreads();
 
-    for (int t = a.t_begin; t < a.t_end; ++t) {
-      const unsigned epoch = (unsigned)(t - a.t_begin + 1);
-      const int u = t + 1;
+    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      const int u = ts + 1;
       // causal conv of the one-hot input = two embedding rows; starts the step
       if (tid < 128) {
         float v = 0.f;
@@ -283,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
         }
         put_granule(outbox + tid, epoch, v);
       }
+      MVN_STAMP(b, s, ts - a.t_begin, 1);
       int next_given = 0;
       if (tid == 0 && u < a.n_given) next_given = samples[u];
       if (wave == 0) {
@@ -296,136 +416,109 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       }
       lds_barrier();
       if (iflag[0] == 0) break;
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
       const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
       const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
       int choice = next_given;
       if (do_head) {
         {
-          const f4 *x4 = (const f4 *)(a0 + 32 * q1);
-          float h0 = 0.f, h1 = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; i += 2) {
-            const f4 xa = x4[i], xb = x4[i + 1];
-            h0 = fmaf(w1[4 * i], xa.x, h0); h0 = fmaf(w1[4 * i + 1], xa.y, h0);
-            h0 = fmaf(w1[4 * i + 2], xa.z, h0); h0 = fmaf(w1[4 * i + 3], xa.w, h0);
-            h1 = fmaf(w1[4 * i + 4], xb.x, h1); h1 = fmaf(w1[4 * i + 5], xb.y, h1);
-            h1 = fmaf(w1[4 * i + 6], xb.z, h1); h1 = fmaf(w1[4 * i + 7], xb.w, h1);
-          }
-          float h = h0 + h1;
-          h += __shfl_xor(h, 1, 64);
-          if (q1 == 0) a1[o1] = leaky(h + b1r);
+          float hsum = dot32(w1, a0 + 32 * q1);
+          hsum += dpp_mov<DPP_XOR1>(hsum);
+          if (q1 == 0) a1[o1] = leaky(hsum + b1r);
         }
         lds_barrier();
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         {
-          const f4 *x4 = (const f4 *)(a1 + 32 * q2);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const f4 x = x4[i];
-            s0 = fmaf(w2[0][4 * i], x.x, s0); s0 = fmaf(w2[0][4 * i + 1], x.y, s0);
-            s0 = fmaf(w2[0][4 * i + 2], x.z, s0); s0 = fmaf(w2[0][4 * i + 3], x.w, s0);
-            s1 = fmaf(w2[1][4 * i], x.x, s1); s1 = fmaf(w2[1][4 * i + 1], x.y, s1);
-            s1 = fmaf(w2[1][4 * i + 2], x.z, s1); s1 = fmaf(w2[1][4 * i + 3], x.w, s1);
-            s2 = fmaf(w2[2][4 * i], x.x, s2); s2 = fmaf(w2[2][4 * i + 1], x.y, s2);
-            s2 = fmaf(w2[2][4 * i + 2], x.z, s2); s2 = fmaf(w2[2][4 * i + 3], x.w, s2);
-            s3 = fmaf(w2[3][4 * i], x.x, s3); s3 = fmaf(w2[3][4 * i + 1], x.y, s3);
-            s3 = fmaf(w2[3][4 * i + 2], x.z, s3); s3 = fmaf(w2[3][4 * i + 3], x.w, s3);
-          }
-#pragma unroll
-          for (int off = 1; off < 8; off <<= 1) {
-            s0 += __shfl_xor(s0, off, 64);
-            s1 += __shfl_xor(s1, off, 64);
-            s2 += __shfl_xor(s2, off, 64);
-            s3 += __shfl_xor(s3, off, 64);
-          }
+          float s0 = dot32(w2[0], a1 + 32 * q2), s1 = dot32(w2[1], a1 + 32 * q2);
+          float s2 = dot32(w2[2], a1 + 32 * q2), s3 = dot32(w2[3], a1 + 32 * q2);
+          s0 = quad_sum(s0); s0 += other_quad(s0);
+          s1 = quad_sum(s1); s1 += other_quad(s1);
+          s2 = quad_sum(s2); s2 += other_quad(s2);
+          s3 = quad_sum(s3); s3 += other_quad(s3);
+          const int sel = q2 & 3;
+          if (q2 < 4) lgb[4 * og + sel] = (sel == 0 ? s0 : sel == 1 ? s1 : sel == 2 ? s2 : s3) + b2r;
         }
-        const int sel = q2 & 3;
-        float lg = (sel == 0 ? s0 : sel == 1 ? s1 : sel == 2 ? s2 : s3) + b2r;
-        if (active && a.logits_out && u >= a.logits_t0)
-          a.logits_out[((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q + cls] = lg;
-        // softmax -> [/T] -> softmax over the 256 active lanes (32 per wave, class order)
-        float m = wave_max(active ? lg : -INFINITY);
-        if (lane == 0) red[wave] = m;
         lds_barrier();
-        m = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])),
-                  fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
-        const float e = active ? expf(lg - m) : 0.f;
-        float sm = wave_sum(e);
-        if (lane == 0) red[8 + wave] = sm;
-        lds_barrier();
-        sm = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
-        float p = e / sm;
-        if (a.temperature > 0.f) p = p / a.temperature;
-        float m2 = wave_max(active ? p : -INFINITY);
-        if (lane == 0) red[16 + wave] = m2;
-        lds_barrier();
-        m2 = fmaxf(fmaxf(fmaxf(red[16], red[17]), fmaxf(red[18], red[19])),
-                   fmaxf(fmaxf(red[20], red[21]), fmaxf(red[22], red[23])));
-        const float e2 = active ? expf(p - m2) : 0.f;
-        float s2sum = wave_sum(e2);
-        if (lane == 0) red[24 + wave] = s2sum;
-        lds_barrier();
-        s2sum = ((red[24] + red[25]) + (red[26] + red[27])) + ((red[28] + red[29]) + (red[30] + red[31]));
-        const float p2 = e2 / s2sum;
+        if (wave == 0) {
+          // one wave finishes the step: lane i owns classes 4i..4i+3, every reduction
+          // is intra-wave (DPP + readlane), no further barrier on the way to the choice
+          const f4 lv = ((const f4 *)lgb)[lane];
+          float lg[4] = {lv.x, lv.y, lv.z, lv.w};
+          if (a.logits_out && u >= a.logits_t0)
+            ((f4 *)(a.logits_out +
+                    ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
+          const float m = wave_max_dpp(fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3])));
+          float e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = expf(lg[k] - m);
+          const float sm = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
+          float p[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            p[k] = e[k] / sm;
+            if (a.temperature > 0.f) p[k] = p[k] / a.temperature;
+          }
+          const float m2 = wave_max_dpp(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = expf(p[k] - m2);
+          const float s2sum = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) p[k] = e[k] / s2sum;  // the distribution generate() uses
 
-        int cand;
-        if (a.temperature > 0.f) {
-          float cdf = p2;  // inactive lanes hold 0: the scan runs in class order
+          int pick;
+          if (a.temperature > 0.f) {
+            const float lsum = (p[0] + p[1]) + (p[2] + p[3]);
+            float incl = lsum;  // inclusive scan of lane totals, class order
 #pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const float n = __shfl_up(cdf, off, 64);
-            if (lane >= off) cdf += n;
-          }
-          if (lane == 63) red[32 + wave] = cdf;
-          lds_barrier();
-          float base = 0.f, total = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) {
-            if (w < wave) base += red[32 + w];
-            total += red[32 + w];
-          }
-          const float target = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b) * total;
-          cand = (active && base + cdf > target) ? cls : Q - 1;
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
-        } else {
-          float bv = active ? p2 : -1.f;
-          cand = active ? cls : Q;
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(cand, off, 64);
-            if (ov > bv || (ov == bv && oi < cand)) {
-              bv = ov;
-              cand = oi;
+            for (int off = 1; off < 64; off <<= 1) {
+              const float n = __shfl_up(incl, off, 64);
+              if (lane >= off) incl += n;
             }
-          }
-          if (lane == 0) red[40 + wave] = bv;
-        }
-        if (lane == 0) ired[wave] = cand;
-        lds_barrier();
-        int pick = ired[0];
-        if (a.temperature > 0.f) {
+            const float total = lane_value(incl, 63);
+            const float target = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b) * total;
+            float cdf = incl - lsum;
+            int cand = Q - 1;
 #pragma unroll
-          for (int w = 1; w < 8; ++w) pick = min(pick, ired[w]);
-        } else {
-          float bv = red[40];
-#pragma unroll
-          for (int w = 1; w < 8; ++w)
-            if (red[40 + w] > bv) {  // waves hold ascending class ranges: strict > keeps the first
-              bv = red[40 + w];
-              pick = ired[w];
+            for (int k = 3; k >= 0; --k) {
+              // walk down so that the smallest qualifying class wins
+              const float c_k = cdf + (k == 0 ? p[0] : k == 1 ? p[0] + p[1]
+                                                      : k == 2 ? (p[0] + p[1]) + p[2]
+                                                               : ((p[0] + p[1]) + p[2]) + p[3]);
+              if (c_k > target) cand = 4 * lane + k;
             }
-        }
-        if (tid == 0) {
-          if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
-          if (u >= a.n_given) {
-            samples[u] = pick;
-            choice = pick;
+            cand = min(cand, dpp_movi<DPP_XOR1>(cand));
+            cand = min(cand, dpp_movi<DPP_XOR2>(cand));
+            cand = min(cand, dpp_movi<DPP_HALF_MIRROR>(cand));
+            cand = min(cand, dpp_movi<DPP_MIRROR>(cand));
+            pick = min(min(__builtin_amdgcn_readlane(cand, 0), __builtin_amdgcn_readlane(cand, 16)),
+                       min(__builtin_amdgcn_readlane(cand, 32), __builtin_amdgcn_readlane(cand, 48)));
+          } else {
+            float bv = p[0];
+            int bi = 4 * lane;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+              if (p[k] > bv) {  // strict: first maximum
+                bv = p[k];
+                bi = 4 * lane + k;
+              }
+            argmax_take(bv, bi, dpp_mov<DPP_XOR1>(bv), dpp_movi<DPP_XOR1>(bi));
+            argmax_take(bv, bi, dpp_mov<DPP_XOR2>(bv), dpp_movi<DPP_XOR2>(bi));
+            argmax_take(bv, bi, dpp_mov<DPP_HALF_MIRROR>(bv), dpp_movi<DPP_HALF_MIRROR>(bi));
+            argmax_take(bv, bi, dpp_mov<DPP_MIRROR>(bv), dpp_movi<DPP_MIRROR>(bi));
+            float rv = lane_value(bv, 0);
+            pick = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+            for (int row = 16; row < 64; row += 16)
+              argmax_take(rv, pick, lane_value(bv, row), __builtin_amdgcn_readlane(bi, row));
+          }
+          if (lane == 0) {
+            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
+            if (u >= a.n_given) {
+              samples[u] = pick;
+              choice = pick;
+            }
           }
         }
       }
-      lds_barrier();
       if (tid == 0) {
         iflag[2] = iflag[1];
         iflag[1] = choice;
@@ -447,14 +540,15 @@ __global__ void pack_layer_p64_kernel(const float *fw, const float *gw, const fl
     dst[i] = o < C ? rb[o] : sb[o - C];
     return;
   }
+  // each matrix: [i8 (8)][t (256)] float4, thread t of its group owns 32 inputs k = 32h + 4*i8 + e
   const int region = i / MAT_F, r = i - region * MAT_F;
-  const int e = r & 3, v = r >> 2, tid = v & (NT - 1), i4 = v >> 9, q = tid & 3;
-  const int k = 16 * q + 4 * i4 + e;
+  const int e = r & 3, v = r >> 2, t = v & 255, i8 = v >> 8, h = t & 1;
+  const int k = 32 * h + 4 * i8 + e;
   if (region < 2) {
-    const int row = ((tid >> 2) & 1) * 64 + (tid >> 3);
+    const int row = ((t >> 1) & 1) * 64 + (t >> 2);
     dst[i] = fg_elem(fw, gw, C, row, region == 0 ? 64 + k : k);  // WC: current tap, WP: past tap
   } else {
-    dst[i] = rs_elem(rw, sw, C, tid >> 2, k);
+    dst[i] = rs_elem(rw, sw, C, t >> 1, k);
   }
 }
 
@@ -541,3 +635,14 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hip
 }
 
 }  // namespace mvn
+
+#ifdef MVN_PIPE_STAMPS
+extern "C" int mvn_debug_read_stamps(unsigned long long *out, size_t n) {
+  if (n > sizeof(mvn::g_stamps) / 8) n = sizeof(mvn::g_stamps) / 8;
+  return mvn::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(mvn::g_stamps), n * 8), "read stamps");
+}
+extern "C" int mvn_debug_read_fine(unsigned long long *out, size_t n) {
+  if (n > sizeof(mvn::g_fine) / 8) n = sizeof(mvn::g_fine) / 8;
+  return mvn::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(mvn::g_fine), n * 8), "read fine");
+}
+#endif
