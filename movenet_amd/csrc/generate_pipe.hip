@@ -64,9 +64,17 @@ __device__ unsigned long long g_fine[16][16][64][8];
 #define MVN_FINE(bb, ss, step, slot, who) do {} while (0)
 #endif
 
-__device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v) {
-  __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+// `same_xcd`: producer and consumer were FOUND (from HW_REG_XCC_ID, exchanged at kernel
+// start) to sit on one XCD.  They then share one L2, so a plain store (write-through L1,
+// line kept in that L2) is seen by the consumer's L1-bypassing polls: ~0.33 us per hop
+// instead of ~0.6.  Otherwise the granule is stored sc1 (write-through to memory), the
+// placement-independent form.  Placement only ever selects between two correct forms.
+__device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v, bool same_xcd) {
+  const u64 x = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+  if (same_xcd)
+    *g = x;
+  else
+    __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Wave 0 only.  Lane i owns granules 2i and 2i+1 of the inbox.  Returns false on
@@ -147,11 +155,21 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define MVN_EXP 0   // timing experiments of scripts/pipe_stamps.py; 0 = the product
 #endif
 
-// 32-term dot product as 16 packed FMAs (v_pk_fma_f32): w and x as 16 float2;
-// two interleaved partial sums (even / odd terms), fixed order.
+// 16-term dot product as 8 packed FMAs (v_pk_fma_f32) in two independent chains,
+// combined in a fixed order.  w: 8 float2, x: 16 consecutive floats in LDS (already
+// fetched as four float4 by the caller).
+__device__ __forceinline__ float dot16(const v2f (&w)[8], const f4 (&x)[4]) {
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a0 = __builtin_elementwise_fma(w[2 * i], v2f{x[i].x, x[i].y}, a0);
+    a1 = __builtin_elementwise_fma(w[2 * i + 1], v2f{x[i].z, x[i].w}, a1);
+  }
+  const v2f t = a0 + a1;
+  return t.x + t.y;
+}
+// 32-term dot product as 16 packed FMAs in four chains (head)
 __device__ __forceinline__ float dot32(const v2f (&w)[16], const float *x) {
-  // four independent accumulation chains (the packed FMA has ~8 cycles of dependent
-  // latency: one chain of 16 would serialise), combined in a fixed order
   const f4 *x4 = (const f4 *)x;
   v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
 #pragma unroll
@@ -173,6 +191,18 @@ __device__ __forceinline__ void load32(v2f (&w)[16], const f4 *src, int stride, 
     w[2 * i + 1] = v2f{v.z, v.w};
   }
 }
+// two rows x 16 inputs: wa <- float4 0..3, wb <- float4 4..7 of a [8][stride] block
+__device__ __forceinline__ void load2x16(v2f (&wa)[8], v2f (&wb)[8], const f4 *src, int stride,
+                                         int idx) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f4 u = src[i * stride + idx], v = src[(4 + i) * stride + idx];
+    wa[2 * i] = v2f{u.x, u.y};
+    wa[2 * i + 1] = v2f{u.z, u.w};
+    wb[2 * i] = v2f{v.x, v.y};
+    wb[2 * i + 1] = v2f{v.z, v.w};
+  }
+}
 
 // (value, index) arg-max combine: larger value wins, smaller index on ties
 __device__ __forceinline__ void argmax_take(float &bv, int &bi, float ov, int oi) {
@@ -192,23 +222,49 @@ __device__ __forceinline__ int dpp_movi(int v) {
 // same bookkeeping instructions, and each thread keeps 4 layers x 32 weights = 128
 // VGPRs resident.
 __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand, unsigned *err,
-                                                           int NS) {
+                                                           int NS, int nb) {
   using namespace p64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / NS, s = blockIdx.x - b * NS;
+  // Workgroups i and i+8 are observed to land on the same XCD: lay the NS stages of a
+  // pipeline out with stride 8 so that its hops stay inside one L2 (speed only; every
+  // edge verifies its placement below).
+  const int slot = blockIdx.x >> 3;
+  const int b = (blockIdx.x & 7) + 8 * (slot / NS), s = slot - (slot / NS) * NS;
+  if (b >= nb) return;
   const int L = a.L;
+  const int s_next = s + 1 == NS ? 0 : s + 1;
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
-  u64 *outbox = hand + ((size_t)b * NS + (s + 1 == NS ? 0 : s + 1)) * GRAN;
+  u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
   int *iflag = (int *)(smem + LDS_FLOATS - 16);  // [0] ok flag, [1] idx_cur, [2] idx_prev
+  // placement handshake: publish my XCC id (+1), read my consumer's
+  bool fast_edge = false;
+  {
+    unsigned *xcc = err + 16;  // [nb * NS] words, zeroed by the launch's memset
+    const unsigned mine = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1;  // HW_REG_XCC_ID[3:0]
+    if (tid == 0) {
+      __hip_atomic_store(xcc + b * NS + s, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned other = 0;
+      for (unsigned spins = 0; spins < (1u << 20) && other == 0; ++spins) {
+        other = __hip_atomic_load(xcc + b * NS + s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other == 0) __builtin_amdgcn_s_sleep(8);
+      }
+      iflag[3] = (other == mine) ? 1 : 0;  // unknown (time-out) => the safe form
+    }
+    __syncthreads();
+    fast_edge = iflag[3] != 0;
+    __syncthreads();
+  }
 
   if (s < NS - 1) {
     // ================= layer stage: layers l0 .. l0+nl-1 =================
+    // FG group thread t: channel c = t>>2, rows f_c and g_c, inputs k in [16kq, 16kq+16);
+    // RS group thread t: channel c = t>>2, rows res_c and skip_c, same k split.  A row is
+    // finished by a 4-lane DPP sum; each lane fetches 16 inputs (4 x ds_read_b128).
     const int l0 = s * LPS, nl = min(LPS, L - l0);
     const bool fg_group = tid < 256;
-    const int t = tid & 255, h = t & 1;
-    const int fc = t >> 2, which = (t >> 1) & 1;  // FG: channel, f|g       (k half = h)
-    const int o = t >> 1;                          // RS: row res 0..63 | skip 64..127
+    const int t = tid & 255, c = t >> 2, kq = t & 3;
+    const bool lead = kq == 0;
     float *wp = smem;                  // [LPS][8][256] float4: past-tap f|g weights (FG group)
     float *cur = smem + LPS * MAT_F;   // [64] residual stream
     float *zb = cur + 64;              // [64] gated activation
@@ -216,24 +272,26 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     float *skin = pastb + LPS * 64;    // [64] running skip sum as received
     float *ring = a.state + (size_t)b * a.state_per_seq;
 
-    v2f w[LPS][16];                    // FG group: current-tap f|g rows; RS group: res|skip rows
-    float bias[LPS], pj[LPS], xs[LPS];
+    v2f wa[LPS][8], wb[LPS][8];        // FG: f_c | g_c current-tap rows; RS: res_c | skip_c rows
+    float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
     int doff[LPS], dmask[LPS];
 #pragma unroll
     for (int j = 0; j < LPS; ++j) {
-      bias[j] = 0.f; pj[j] = 0.f; xs[j] = 0.f; doff[j] = 0; dmask[j] = 0;
+      bias_r[j] = 0.f; bias_s[j] = 0.f; pf[j] = 0.f; pg[j] = 0.f; xs[j] = 0.f;
+      doff[j] = 0; dmask[j] = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) w[j][i] = v2f{0.f, 0.f};
+      for (int i = 0; i < 8; ++i) { wa[j][i] = v2f{0.f, 0.f}; wb[j][i] = v2f{0.f, 0.f}; }
       if (j < nl) {
         const float *lw = a.w + EMB_F + (size_t)(l0 + j) * LAYER_F;
         if (fg_group) {
-          load32(w[j], (const f4 *)lw, 256, t);
+          load2x16(wa[j], wb[j], (const f4 *)lw, 256, t);
           const f4 *wp4 = (const f4 *)(lw + MAT_F);
 #pragma unroll
           for (int i = 0; i < 8; ++i) ((f4 *)wp)[(j * 8 + i) * 256 + t] = wp4[i * 256 + t];
         } else {
-          load32(w[j], (const f4 *)(lw + 2 * MAT_F), 256, t);
-          bias[j] = lw[3 * MAT_F + o];
+          load2x16(wa[j], wb[j], (const f4 *)(lw + 2 * MAT_F), 256, t);
+          bias_r[j] = lw[3 * MAT_F + c];
+          bias_s[j] = lw[3 * MAT_F + 64 + c];
         }
         const int l = l0 + j;
         dmask[j] = (1 << (l % a.layer_size)) - 1;
@@ -242,17 +300,17 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     }
 
     // Off the critical path: push this step's layer inputs into the dilation queues,
-    // pop the entries step tn needs (RS lanes), then the past-tap half of step tn's
-    // f/g pre-activations (FG group).
+    // pop the entries step tn needs (RS lead lanes), then the past-tap half of step
+    // tn's f/g pre-activations (FG group).
     auto precompute = [&](int tn, bool push) {
-      if (!fg_group && h == 0 && o < 64) {
+      if (!fg_group && lead) {
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
           if (j < nl) {
-            float *base = ring + doff[j] + o;
+            float *base = ring + doff[j] + c;
             if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
             const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
-            pastb[j * 64 + o] = pv;
+            pastb[j * 64 + c] = pv;
           }
       }
       __syncthreads();
@@ -260,11 +318,12 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
           if (j < nl) {
-            v2f wq[16];
-            load32(wq, (const f4 *)wp + j * 8 * 256, 256, t);
-            float p = dot32(wq, pastb + j * 64 + 32 * h);
-            p += dpp_mov<DPP_XOR1>(p);
-            pj[j] = p;
+            v2f qa[8], qb[8];
+            load2x16(qa, qb, (const f4 *)wp + j * 8 * 256, 256, t);
+            const f4 *x4 = (const f4 *)(pastb + j * 64 + 16 * kq);
+            const f4 x[4] = {x4[0], x4[1], x4[2], x4[3]};
+            pf[j] = quad_sum(dot16(qa, x));
+            pg[j] = quad_sum(dot16(qb, x));
           }
       }
     };
@@ -285,72 +344,55 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
       lds_barrier();
-      if (iflag[0] == 0) break;
       MVN_STAMP(b, s, ts - a.t_begin, 0);
-      float skipacc = (!fg_group && h == 0 && o >= 64) ? skin[o - 64] : 0.f;
+      float skipacc = (!fg_group && lead) ? skin[c] : 0.f;
 #pragma unroll
       for (int j = 0; j < LPS; ++j)
         if (j < nl) {
           float old = 0.f;
-          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 0, 0);
           if (fg_group) {
-            // f|g row: current-tap product over this lane's 32 inputs + other half + past half
-#if MVN_EXP == 3
-            float p = cur[32 * h] * w[j][0].x;
-#else
-            float p = dot32(w[j], cur + 32 * h);
-#endif
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 1, 0);
-            p += dpp_mov<DPP_XOR1>(p);
-            p += pj[j];
-            const float g = dpp_mov<DPP_XOR2>(p);  // f lanes (which == 0) receive g
+            const f4 *x4 = (const f4 *)(cur + 16 * kq);
+            const f4 x[4] = {x4[0], x4[1], x4[2], x4[3]};
+            const float f = quad_sum(dot16(wa[j], x)) + pf[j];
+            const float g = quad_sum(dot16(wb[j], x)) + pg[j];
 #if MVN_EXP == 1
-            const float z = p + g;
+            const float z = f + g;
 #else
-            const float z = gate_fast(p, g);
+            const float z = gate_fast(f, g);
 #endif
-            if ((t & 3) == 0) zb[fc] = z;
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 0);
-          } else if (h == 0 && o < 64) {
-            old = cur[o];  // this layer's input: residual add below, queue push later
+            if (lead) zb[c] = z;
+          } else if (lead) {
+            old = cur[c];  // this layer's input: residual add below, queue push later
           }
           lds_barrier();
-          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 256);
           if (!fg_group) {
-#if MVN_EXP == 3
-            float r = zb[32 * h] * w[j][0].x;
-#else
-            float r = dot32(w[j], zb + 32 * h);
-#endif
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 4, 256);
-            r += dpp_mov<DPP_XOR1>(r);
-            if (h == 0) {
-              const float v = r + bias[j];
-              float outv;
-              if (o < 64) {
-                xs[j] = old;
-                outv = v + old;
-                cur[o] = outv;
-              } else {
-                skipacc += v;
-                outv = skipacc;
+            const f4 *z4 = (const f4 *)(zb + 16 * kq);
+            const f4 x[4] = {z4[0], z4[1], z4[2], z4[3]};
+            const float r = quad_sum(dot16(wa[j], x));
+            const float k = quad_sum(dot16(wb[j], x));
+            if (lead) {
+              xs[j] = old;
+              const float outv = (r + bias_r[j]) + old;
+              cur[c] = outv;
+              skipacc += k + bias_s[j];
+              if (j == nl - 1) {
+                // the stage's last layer: hand the activation on before anything else
+                put_granule(outbox + c, epoch, outv, fast_edge);
+                put_granule(outbox + 64 + c, epoch, skipacc, fast_edge);
               }
-              // the stage's last layer: hand the activation on before anything else
-              if (j == nl - 1) put_granule(outbox + o, epoch, outv);
             }
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 5, 256);
           }
           lds_barrier();
-          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 6, 0);
         }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
+      if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
       if (ts + 1 < a.t_end) {
         precompute(ts + 1, true);
-      } else if (!fg_group && h == 0 && o < 64) {
+      } else if (!fg_group && lead) {
         // last step of the launch: push only (the next launch pops in its prologue)
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
-          if (j < nl) ring[doff[j] + o + (ts & dmask[j]) * C] = xs[j];
+          if (j < nl) ring[doff[j] + c + (ts & dmask[j]) * C] = xs[j];
       }
     }
     return;
@@ -400,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
           v = E1[ic * C + tid];
           if (ip >= 0) v += E0[ip * C + tid];
         }
-        put_granule(outbox + tid, epoch, v);
+        put_granule(outbox + tid, epoch, v, fast_edge);
       }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
       int next_given = 0;
@@ -415,7 +457,6 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
       lds_barrier();
-      if (iflag[0] == 0) break;
       MVN_STAMP(b, s, ts - a.t_begin, 0);
       const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
       const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
@@ -449,20 +490,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
           const float m = wave_max_dpp(fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3])));
           float e[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) e[k] = expf(lg[k] - m);
+          for (int k = 0; k < 4; ++k) e[k] = __expf(lg[k] - m);
           const float sm = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
+          // v_exp_f32 / v_rcp_f32 forms (1-2 ulp): the choice depends on the ORDER of
+          // the probabilities, which these monotone maps preserve
+          const float rs = __builtin_amdgcn_rcpf(sm) *
+                           (a.temperature > 0.f ? __builtin_amdgcn_rcpf(a.temperature) : 1.0f);
           float p[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            p[k] = e[k] / sm;
-            if (a.temperature > 0.f) p[k] = p[k] / a.temperature;
-          }
+          for (int k = 0; k < 4; ++k) p[k] = e[k] * rs;
           const float m2 = wave_max_dpp(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
 #pragma unroll
-          for (int k = 0; k < 4; ++k) e[k] = expf(p[k] - m2);
+          for (int k = 0; k < 4; ++k) e[k] = __expf(p[k] - m2);
           const float s2sum = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
+          const float rs2 = __builtin_amdgcn_rcpf(s2sum);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) p[k] = e[k] / s2sum;  // the distribution generate() uses
+          for (int k = 0; k < 4; ++k) p[k] = e[k] * rs2;  // the distribution generate() uses
 
           int pick;
           if (a.temperature > 0.f) {
@@ -524,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
         iflag[1] = choice;
       }
       lds_barrier();
+      if (iflag[0] == 0) break;  // hand-off timed out
     }
   }
 }
@@ -540,16 +584,15 @@ __global__ void pack_layer_p64_kernel(const float *fw, const float *gw, const fl
     dst[i] = o < C ? rb[o] : sb[o - C];
     return;
   }
-  // each matrix: [i8 (8)][t (256)] float4, thread t of its group owns 32 inputs k = 32h + 4*i8 + e
+  // each matrix: [i8 (8)][t (256)] float4; thread t = 4*c + kq owns rows (c, 64+c) x inputs
+  // k = 16*kq + 4*(i8 & 3) + e: float4 0..3 belong to row c, 4..7 to row 64+c
   const int region = i / MAT_F, r = i - region * MAT_F;
-  const int e = r & 3, v = r >> 2, t = v & 255, i8 = v >> 8, h = t & 1;
-  const int k = 32 * h + 4 * i8 + e;
-  if (region < 2) {
-    const int row = ((t >> 1) & 1) * 64 + (t >> 2);
+  const int e = r & 3, v = r >> 2, t = v & 255, i8 = v >> 8;
+  const int row = (i8 >> 2) * 64 + (t >> 2), k = 16 * (t & 3) + 4 * (i8 & 3) + e;
+  if (region < 2)
     dst[i] = fg_elem(fw, gw, C, row, region == 0 ? 64 + k : k);  // WC: current tap, WP: past tap
-  } else {
-    dst[i] = rs_elem(rw, sw, C, t >> 1, k);
-  }
+  else
+    dst[i] = rs_elem(rw, sw, C, row, k);
 }
 
 __global__ void pack_head_p64_kernel(const float *w1, const float *b1, const float *w2,
@@ -584,8 +627,10 @@ bool pipe_ok(const mvn_dims *d) {
 }
 int pipe_stages(const mvn_dims *d) { return (n_layers(d) + p64::LPS - 1) / p64::LPS + 1; }
 size_t pipe_hand_floats(const mvn_dims *d, int batch) {
-  // batch * NS inboxes of 128 granules (2 floats each) + 64 floats of flags
-  return (size_t)batch * pipe_stages(d) * p64::GRAN * 2 + 64;
+  // batch * NS inboxes of 128 granules (2 floats each), then 16 flag words (error word
+  // first) and batch * NS placement words, padded to 64 floats
+  const size_t n = (size_t)batch * pipe_stages(d);
+  return n * p64::GRAN * 2 + (16 + n + 63) / 64 * 64;
 }
 
 int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {
@@ -629,8 +674,10 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hip
   if (rc) return rc;
   u64 *gran = (u64 *)hand;
   unsigned *err = (unsigned *)(hand + (size_t)batch * NS * GRAN * 2);
-  hipLaunchKernelGGL(gen_pipe64_kernel, dim3(batch * NS), dim3(NT), LDS_FLOATS * sizeof(float), s, a,
-                     gran, err, NS);
+  // grid: ceil(batch/8) groups of NS slots, 8 workgroups (one per XCD) per slot
+  const int groups = (batch + 7) / 8;
+  hipLaunchKernelGGL(gen_pipe64_kernel, dim3(groups * NS * 8), dim3(NT), LDS_FLOATS * sizeof(float),
+                     s, a, gran, err, NS, batch);
   return check_hip(hipGetLastError(), "mvn_generate(pipe)");
 }
 

@@ -126,8 +126,9 @@ class RingGenerator:
         pipeline not co-resident, e.g. another kernel occupying the CUs)."""
         torch.cuda.current_stream(self.device).synchronize()
         if self.variant == N.GEN_PIPE:
-            flags = self.state[-64:]
-            if int(flags.view(torch.int32)[0].item()) != 0:
+            n_stage = (self.n_layers + 3) // 4 + 1
+            word = self._queue_floats + self.batch * n_stage * 256  # error word follows the inboxes
+            if int(self.state[word:word + 1].view(torch.int32)[0].item()) != 0:
                 raise RuntimeError("movenet_amd: PIPE generator hand-off timed out")
 
     def _run(self, t_begin: int, t_end: int, n_given: int, logits_out=None, choices_out=None,

@@ -59,7 +59,7 @@ def test_generate_sizes_and_variants():
     # dilation queues: D*C floats per sequence (786 KB fp32) + the PIPE
     # variant's hand-off area (9 stages x 128 eight-byte granules per sequence + flags)
     assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 9 * 256 + 64
-    assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 9 * 256) + 64
+    assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 9 * 256) + 192
     assert lib.mvn_gen_state_floats(d1, 2) == 2 * 6 * 16
 
 
