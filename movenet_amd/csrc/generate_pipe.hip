@@ -423,31 +423,35 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     for (int r = 0; r < 4; ++r) load32(w2[r], W2p + r * 8 * NT, NT, tid);
     const float b1r = b1[o1];
     const float b2r = b2[4 * og + (q2 & 3)];
-    f4 b2l = {0.f, 0.f, 0.f, 0.f};
-    if (wave == 0) b2l = ((const f4 *)b2)[lane];
-    if (tid == 0) {
-      iflag[1] = samples[a.t_begin];
-      iflag[2] = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
-    }
     __syncthreads();
+
+    // Wave 0 closes every step alone (softmax, choice) and immediately opens the next
+    // one: it gathers the two embedding rows of the causal conv (modules.py:28-30 on a
+    // one-hot input) and hands them to stage 0, so no barrier sits between the choice
+    // and the next step's first hop.
+    int idx_cur = 0, idx_prev = -1;
+    auto send_h0 = [&](unsigned ep) {  // wave 0: granule `lane` = residual, 64+lane = skip sum 0
+      const int ic = min(max(idx_cur, 0), Q - 1), ip = min(idx_prev, Q - 1);
+      float v = E1[ic * C + lane];
+      if (ip >= 0) v += E0[ip * C + lane];
+      put_granule(outbox + lane, ep, v, fast_edge);
+      put_granule(outbox + 64 + lane, ep, 0.f, fast_edge);
+    };
+    if (wave == 0) {
+      idx_cur = samples[a.t_begin];
+      idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
+      if (a.t_begin < a.t_end) send_h0(1u);
+      MVN_STAMP(b, s, 0, 1);
+    }
 
     for (int ts = a.t_begin; ts < a.t_end; ++ts) {
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       const int u = ts + 1;
-      // causal conv of the one-hot input = two embedding rows; starts the step
-      if (tid < 128) {
-        float v = 0.f;
-        if (tid < 64) {
-          const int ic = min(max(iflag[1], 0), Q - 1), ip = min(iflag[2], Q - 1);
-          v = E1[ic * C + tid];
-          if (ip >= 0) v += E0[ip * C + tid];
-        }
-        put_granule(outbox + tid, epoch, v, fast_edge);
-      }
-      MVN_STAMP(b, s, ts - a.t_begin, 1);
-      int next_given = 0;
-      if (tid == 0 && u < a.n_given) next_given = samples[u];
+      const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
+      const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
+      int next_idx = 0;
       if (wave == 0) {
+        if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
         float v0, v1;
         const bool ok = wait_inbox(inbox, epoch, err, v0, v1);
         if (ok && lane >= 32) {
@@ -458,9 +462,6 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
-      const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
-      const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
-      int choice = next_given;
       if (do_head) {
         {
           float hsum = dot32(w1, a0 + 32 * q1);
@@ -479,9 +480,10 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
           if (q2 < 4) lgb[4 * og + sel] = (sel == 0 ? s0 : sel == 1 ? s1 : sel == 2 ? s2 : s3) + b2r;
         }
         lds_barrier();
-        if (wave == 0) {
-          // one wave finishes the step: lane i owns classes 4i..4i+3, every reduction
-          // is intra-wave (DPP + readlane), no further barrier on the way to the choice
+      }
+      if (wave == 0) {
+        if (do_head) {
+          // lane i owns classes 4i..4i+3; every reduction is intra-wave (DPP + readlane)
           const f4 lv = ((const f4 *)lgb)[lane];
           float lg[4] = {lv.x, lv.y, lv.z, lv.w};
           if (a.logits_out && u >= a.logits_t0)
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
             }
             const float total = lane_value(incl, 63);
             const float target = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b) * total;
-            float cdf = incl - lsum;
+            const float cdf = incl - lsum;
             int cand = Q - 1;
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
@@ -553,20 +555,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
             for (int row = 16; row < 64; row += 16)
               argmax_take(rv, pick, lane_value(bv, row), __builtin_amdgcn_readlane(bi, row));
           }
+          if (u >= a.n_given) next_idx = pick;
+          idx_prev = idx_cur;
+          idx_cur = next_idx;
+          if (ts + 1 < a.t_end) send_h0(epoch + 1);
+          MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
           if (lane == 0) {
             if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
-            if (u >= a.n_given) {
-              samples[u] = pick;
-              choice = pick;
-            }
+            if (u >= a.n_given) samples[u] = pick;
           }
+        } else {
+          idx_prev = idx_cur;
+          idx_cur = next_idx;
+          if (ts + 1 < a.t_end) send_h0(epoch + 1);
+          MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
         }
       }
-      if (tid == 0) {
-        iflag[2] = iflag[1];
-        iflag[1] = choice;
-      }
-      lds_barrier();
       if (iflag[0] == 0) break;  // hand-off timed out
     }
   }
