@@ -167,10 +167,35 @@ struct RsOp {
   }
   __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
                                            const f32x16 &a1) const {
+    const int m0 = mb * 64 + 4 * (lane >> 5);
+    if (m0 + 64 <= C) {  // the whole 64-row block is residual rows (block-uniform)
+      if (!xout.p) return;
+      const float *xi = xin.at(b, m0, t);
+      float *xo = xout.at(b, m0, t);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2);
+        xo[(size_t)dm * xout.ld] = (a0[r] + br[m0 + dm]) + xi[(size_t)dm * xin.ld];
+        xo[(size_t)(dm + 32) * xout.ld] = (a1[r] + br[m0 + 32 + dm]) + xi[(size_t)(dm + 32) * xin.ld];
+      }
+    } else if (mb * 64 >= C && mb * 64 + 64 <= C + Kc) {  // the whole block is skip rows
+      if (t < t_skip0) return;
+      const int k0 = m0 - C;
+      float *sp = skip.at(b, k0, t - t_skip0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2);
+        float *s0 = sp + (size_t)dm * skip.ld, *s1 = sp + (size_t)(dm + 32) * skip.ld;
+        const float v0 = a0[r] + bs[k0 + dm], v1 = a1[r] + bs[k0 + 32 + dm];
+        *s0 = first_layer ? v0 : *s0 + v0;
+        *s1 = first_layer ? v1 : *s1 + v1;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
+        one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      }
     }
   }
 };
@@ -238,10 +263,27 @@ struct DzOp {
   }
   __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
                                            const f32x16 &a1) const {
+    const int m0 = mb * 64 + 4 * (lane >> 5);
+    if (mb * 64 + 64 <= C) {  // every row of the block is a real channel (block-uniform)
+      const float *tp = th.at(b, m0, t), *sp = sg.at(b, m0, t);
+      float *df = dfg.at(b, m0, t), *dg = dfg.at(b, C + m0, t);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const size_t dm = (size_t)((r & 3) + 8 * (r >> 2) + 32 * hh);
+          const float dz = hh ? a1[r] : a0[r];
+          const float tv = tp[dm * th.ld], sv = sp[dm * sg.ld];
+          df[dm * dfg.ld] = dz * sv * (1.0f - tv * tv);
+          dg[dm * dfg.ld] = dz * tv * sv * (1.0f - sv);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
+        one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      }
     }
   }
 };
@@ -284,44 +326,65 @@ struct DxOp {
 // wave one 32x32 MFMA tile, K = time.  Grid: (time chunks * B, M/64 * N/64).
 // ======================================================================
 constexpr int WG_T = 64;       // time per LDS tile
-constexpr int WG_CHUNK = 2048;  // time per block
+constexpr int WG_CHUNK = 512;  // time per workgroup (8 tiles): >= 900 workgroups at config 2
 
+// bias_part: optional scratch [gridDim.x][64 * (M blocks)] -- every workgroup with
+// nblk == 0 stores its 64 row sums there and bias_reduce_kernel adds them up in a
+// fixed order.  (Atomics straight into the 64..256 bias words serialise: ~800
+// workgroups on four cache lines made this kernel 3x slower.)
 template <class Op>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int chunks_per_b) {
-  __shared__ float As[64][WG_T + 1];
-  __shared__ float Xs[64][WG_T + 1];
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int chunks_per_b,
+                                                      float *__restrict__ bias_part, int m_rows64) {
+  __shared__ float As[2][64][WG_T + 1];
+  __shared__ float Xs[2][64][WG_T + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
   const int mi = wave >> 1, ni = wave & 1;
   const int tb = op.t_begin + ch * WG_CHUNK, te = min(op.t_end, tb + WG_CHUNK);
+  const bool want_bias = nblk == 0;
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float bsum = 0.f;
-
-  for (int t0 = tb; t0 < te; t0 += WG_T) {
-    // 64 rows x 64 t per operand: wave w loads rows w, w+4, ...
-#pragma unroll 4
+  // wave w stages rows w, w+4, ..., w+60 (lane = time): 16 + 16 values per thread
+  float areg[16], xreg[16], bsum[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
+  auto gload = [&](int t0) {
+    const int t = t0 + lane;
+    const bool ok = t < te;
+#pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int row = wave + 4 * j, t = t0 + lane;
-      const bool ok = t < te;
-      As[row][lane] = ok ? op.a(b, mblk * 64 + row, t) : 0.f;
-      Xs[row][lane] = ok ? op.x(b, nblk * 64 + row, t) : 0.f;
+      const int row = wave + 4 * j;
+      areg[j] = ok ? op.a(b, mblk * 64 + row, t) : 0.f;
+      xreg[j] = ok ? op.x(b, nblk * 64 + row, t) : 0.f;
     }
-    __syncthreads();
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      As[buf][wave + 4 * j][lane] = areg[j];
+      Xs[buf][wave + 4 * j][lane] = xreg[j];
+      bsum[j] += areg[j];  // bias gradient = row sums of A, folded into the staging pass
+    }
+  };
+
+  gload(tb);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int t0 = tb; t0 < te; t0 += WG_T, buf ^= 1) {
+    const bool more = t0 + WG_T < te;
+    if (more) gload(t0 + WG_T);  // next tile's global loads fly under this tile's MFMAs
 #pragma unroll 8
     for (int kk = 0; kk < WG_T / 2; ++kk) {
       const int tc = 2 * kk + (lane >> 5);
-      const float av = As[32 * mi + (lane & 31)][tc];
-      const float xv = Xs[32 * ni + (lane & 31)][tc];
+      const float av = As[buf][32 * mi + (lane & 31)][tc];
+      const float xv = Xs[buf][32 * ni + (lane & 31)][tc];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
     }
-    if (nblk == 0 && tid < 64) {
-#pragma unroll 8
-      for (int t = 0; t < WG_T; ++t) bsum += As[tid][t];
-    }
+    if (more) lstore(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
@@ -330,10 +393,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int ch
     float *dst = op.dw(m, n);
     if (dst) atomicAdd(dst, acc[r]);
   }
-  if (nblk == 0 && tid < 64) {
-    float *dst = op.db(mblk * 64 + tid);
-    if (dst) atomicAdd(dst, bsum);
+  if (want_bias) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float v = wave_sum(bsum[j]);
+      const int m = mblk * 64 + wave + 4 * j;
+      if (lane == 0) {
+        if (bias_part) {
+          bias_part[(size_t)blockIdx.x * m_rows64 + m] = v;
+        } else {  // scratch too small for this shape: contended but correct
+          float *dst = op.db(m);
+          if (dst) atomicAdd(dst, v);
+        }
+      }
+    }
   }
+}
+
+// one wave per bias word: lane-strided partial sums in a fixed order, then a wave sum
+template <class Op>
+__global__ void bias_reduce_kernel(Op op, const float *__restrict__ bias_part, int nparts,
+                                   int m_rows64) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  float *dst = op.db(m);
+  if (!dst) return;
+  float s = 0.f;
+  for (int p = lane; p < nparts; p += 64) s += bias_part[(size_t)p * m_rows64 + m];
+  s = wave_sum(s);
+  if (lane == 0) *dst += s;
 }
 
 // dWf/dWg: A = dfg rows (f | g), X = layer input (past | cur) -> (C,C,2) taps
@@ -368,9 +455,16 @@ struct WgRsOp {
     return 0.f;
   }
   __device__ __forceinline__ float x(int b, int n, int t) const {
+#if defined(MVN_EXP) && MVN_EXP == 6
+    return n < C ? *th.at(b, n, t) : 0.f;
+#else
     return n < C ? *th.at(b, n, t) * *sg.at(b, n, t) : 0.f;
+#endif
   }
   __device__ __forceinline__ float *dw(int m, int n) const {
+#if defined(MVN_EXP) && MVN_EXP == 7
+    return nullptr;
+#endif
     if (n >= C) return nullptr;
     if (m < C) return dxo.p ? dwr + (size_t)m * C + n : nullptr;
     if (m < C + Kc) return dws + (size_t)(m - C) * C + n;
@@ -531,14 +625,19 @@ static void launch_gemm(const Op &op, int m_rows, int batch, hipStream_t s) {
   hipLaunchKernelGGL(gemm_wx_kernel<Op>, grid, dim3(256), 0, s, op);
 }
 
+// bias_scratch: >= chunks*batch*64*ceil(m_rows/64) floats, or NULL when the op has no bias
 template <class Op>
-static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, hipStream_t s) {
+static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, float *bias_scratch,
+                         hipStream_t s) {
   const int nt = op.t_end - op.t_begin;
   if (nt <= 0 || batch <= 0) return;
   const int chunks = (nt + WG_CHUNK - 1) / WG_CHUNK;
   const int mb = (m_rows + 63) / 64, nb = (n_rows + 63) / 64;
   dim3 grid(chunks * batch, mb * nb);
-  hipLaunchKernelGGL(wgrad_kernel<Op>, grid, dim3(256), 0, s, op, nb, chunks);
+  hipLaunchKernelGGL(wgrad_kernel<Op>, grid, dim3(256), 0, s, op, nb, chunks, bias_scratch, mb * 64);
+  if (bias_scratch)
+    hipLaunchKernelGGL(bias_reduce_kernel<Op>, dim3(mb * 64), dim3(64), 0, s, op, bias_scratch,
+                       chunks * batch, mb * 64);
 }
 
 }  // namespace mvn
@@ -638,6 +737,15 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
 
   Act dlog = act_view(bwd->dlogit, batch, Q, g.Sp);
   Act da1 = act_view(bwd->da1, batch, Q, g.Sp);
+  // per-workgroup bias partial sums live in the dfg scratch (free until the layer loop
+  // needs it: each use below is followed by its reduce before dfg is written)
+  float *bias_scratch = bwd->dfg;
+  {
+    const size_t need_head = (size_t)((g.S + WG_CHUNK - 1) / WG_CHUNK) * batch * ((Q + 63) / 64 * 64);
+    const size_t need_layer = (size_t)((T + WG_CHUNK - 1) / WG_CHUNK) * batch * ((C + Kc + 63) / 64 * 64);
+    const size_t have = (size_t)batch * 2 * C * g.Tp;
+    if (need_head > have || need_layer > have) bias_scratch = nullptr;
+  }
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
@@ -647,7 +755,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     WgDenseOp<IN_ID> w2;
     w2.t_begin = 0; w2.t_end = g.S; w2.M = Q; w2.N = Q; w2.aact = dlog; w2.xact = a1v;
     w2.dwm = gr->head2_w; w2.dbv = gr->head2_b;
-    launch_wgrad(w2, Q, Q, batch, s);
+    launch_wgrad(w2, Q, Q, batch, bias_scratch, s);
     DenseOp<IN_ID, OUT_MUL_DLRELU, true> d2;
     d2.K = Q; d2.t_begin = 0; d2.t_end = g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
     d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.S;
@@ -657,7 +765,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     WgDenseOp<IN_LRELU> w1;
     w1.t_begin = 0; w1.t_end = g.S; w1.M = Q; w1.N = Kc; w1.aact = da1; w1.xact = skipv;
     w1.dwm = gr->head1_w; w1.dbv = gr->head1_b;
-    launch_wgrad(w1, Q, Kc, batch, s);
+    launch_wgrad(w1, Q, Kc, batch, bias_scratch, s);
     DenseOp<IN_ID, OUT_MUL_DLRELU, true> d1;
     d1.K = Q; d1.t_begin = 0; d1.t_end = g.S; d1.M = Kc; d1.wmat = p->head1_w; d1.ldw = Kc;
     d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.S;
@@ -687,7 +795,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     wr.dxo = dxo; wr.dskip = dskip; wr.th = th; wr.sg = sg;
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
-    launch_wgrad(wr, C + Kc, C, batch, s);
+    launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s);
     DzOp dz;
     dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
     dz.wr = p->residual_w[l]; dz.ws = p->skip_w[l];
@@ -696,7 +804,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     WgFgOp wf;
     wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin;
     wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
-    launch_wgrad(wf, 2 * C, 2 * C, batch, s);
+    launch_wgrad(wf, 2 * C, 2 * C, batch, nullptr, s);
     DxOp dx;
     dx.K = 4 * C; dx.t_begin = A_lo[l]; dx.t_end = T; dx.C = C; dx.d = d; dx.t_lo = t_lo;
     dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];
