@@ -161,6 +161,11 @@ typedef struct mvn_fwd_buffers {
   float *z;     /* (B, C, Tp) gated activation scratch                          */
   float *skip;  /* (B, K, Sp) sum of skips                                      */
   float *a1;    /* (B, Q, Sp) head hidden activation lrelu(conv1(lrelu(skip)))  */
+  const float *ctx; /* optional local conditioning (B, C, ctx_ld), column t = time t
+                       (output of mvn_upsample_video); NULL = audio only.  BUILD
+                       DEFINITION of the alignment: the reference raises at
+                       modules.py:75-77                          */
+  int32_t ctx_ld;
 } mvn_fwd_buffers;
 
 /* out: (B, Q, S_out) contiguous, S_out = S - (remove_last ? 1 : 0); softmax over
@@ -184,6 +189,10 @@ typedef struct mvn_param_grads {
   float *head1_b;
   float *head2_w;
   float *head2_b;
+  float *const *ctx_filter_w; /* only used (and required) when fwd->ctx != NULL */
+  float *const *ctx_filter_b;
+  float *const *ctx_gate_w;
+  float *const *ctx_gate_b;
 } mvn_param_grads;
 
 /* Scratch for the backward pass (floats). */
@@ -194,6 +203,7 @@ typedef struct mvn_bwd_buffers {
   float *dskip;  /* (B, K, Sp) */
   float *da1;    /* (B, Q, Sp) */
   float *dlogit; /* (B, Q, Sp) */
+  float *dctx;   /* (B, C, Tp) gradient w.r.t. fwd->ctx (written); NULL when audio only */
 } mvn_bwd_buffers;
 
 /* dout: gradient w.r.t. mvn_forward's `out` (same shape); `out` itself is needed
@@ -202,6 +212,38 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *params, const mvn_param
                  const int32_t *index, int index_stride, int batch, int t_len,
                  const mvn_fwd_buffers *fwd, const mvn_bwd_buffers *bwd, const float *out,
                  const float *dout, int normalize, int remove_last, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Local conditioning: video encoder + learned upsampler (movenet/wavenet.py:94-118,
+ * :149-156).  video (B, F, 64, 64, Cin) fp32 -> Conv3d(k=(1,64,64)) -> (B, C, F)
+ * -> 3 x ConvTranspose1d(k=10, stride=10) -> ctx (B, C, 1000 F).
+ * Intermediates are caller-provided (B, C, mvn_padded_len(n)) buffers with
+ * n = F, 10 F, 100 F; ctx has row stride ctx_ld >= 1000 F.
+ * ------------------------------------------------------------------------ */
+typedef struct mvn_video_params {
+  const float *conv_w;   /* video_conv.weight (C, Cin, 1, 64, 64) */
+  const float *conv_b;   /* video_conv.bias   (C)                 */
+  const float *up_w[3];  /* video_transpose.{0,1,2}.weight (C, C, 10) = (in, out, tap) */
+  const float *up_b[3];  /* video_transpose.{0,1,2}.bias   (C)    */
+} mvn_video_params;
+
+typedef struct mvn_video_grads { /* accumulated into */
+  float *conv_w;
+  float *conv_b;
+  float *up_w[3];
+  float *up_b[3];
+} mvn_video_grads;
+
+int mvn_upsample_video(const mvn_dims *dims, const mvn_video_params *vp, const float *video,
+                       int batch, int frames, int cin, float *enc, float *u1, float *u2, float *ctx,
+                       int ctx_ld, void *stream);
+
+/* d_u2, d_u1, d_enc: scratch of the same shapes as u2, u1, enc. */
+int mvn_upsample_video_backward(const mvn_dims *dims, const mvn_video_params *vp,
+                                const mvn_video_grads *vg, const float *video, int batch, int frames,
+                                int cin, const float *enc, const float *u1, const float *u2,
+                                const float *dctx, int dctx_ld, float *d_u2, float *d_u1,
+                                float *d_enc, void *stream);
 
 /* Fill the generator's dilation queues from a saved forward (acts of a prompt
  * of t_len >= RF samples): equivalent to mvn_generate over t in [0, t_len-1). */

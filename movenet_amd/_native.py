@@ -60,7 +60,7 @@ _FP = C.POINTER(C.c_void_p)
 
 class FwdBuffers(C.Structure):
     _fields_ = [("acts", C.c_void_p), ("th", C.c_void_p), ("sg", C.c_void_p), ("z", C.c_void_p),
-                ("skip", C.c_void_p), ("a1", C.c_void_p)]
+                ("skip", C.c_void_p), ("a1", C.c_void_p), ("ctx", C.c_void_p), ("ctx_ld", C.c_int32)]
 
 
 class ParamGrads(C.Structure):
@@ -71,12 +71,20 @@ class ParamGrads(C.Structure):
         ("skip_w", _PP), ("skip_b", _PP),
         ("head1_w", C.c_void_p), ("head1_b", C.c_void_p),
         ("head2_w", C.c_void_p), ("head2_b", C.c_void_p),
+        ("ctx_filter_w", _PP), ("ctx_filter_b", _PP),
+        ("ctx_gate_w", _PP), ("ctx_gate_b", _PP),
     ]
 
 
 class BwdBuffers(C.Structure):
     _fields_ = [("dx_a", C.c_void_p), ("dx_b", C.c_void_p), ("dfg", C.c_void_p),
-                ("dskip", C.c_void_p), ("da1", C.c_void_p), ("dlogit", C.c_void_p)]
+                ("dskip", C.c_void_p), ("da1", C.c_void_p), ("dlogit", C.c_void_p),
+                ("dctx", C.c_void_p)]
+
+
+class VideoParams(C.Structure):  # also used for mvn_video_grads (same layout)
+    _fields_ = [("conv_w", C.c_void_p), ("conv_b", C.c_void_p),
+                ("up_w", C.c_void_p * 3), ("up_b", C.c_void_p * 3)]
 
 
 # name -> (restype, argtypes); tests/test_capi.py checks the header against this
@@ -101,6 +109,14 @@ SIGNATURES = {
                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FwdBuffers),
                                C.POINTER(BwdBuffers), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                C.c_void_p]),
+    "mvn_upsample_video": (C.c_int, [C.POINTER(Dims), C.POINTER(VideoParams), C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p]),
+    "mvn_upsample_video_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(VideoParams),
+                                              C.POINTER(VideoParams), C.c_void_p, C.c_int, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
     "mvn_gen_prime_from_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(FwdBuffers), C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "mvn_onehot_to_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

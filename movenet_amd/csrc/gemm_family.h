@@ -1,0 +1,225 @@
+// The two MFMA kernel families every convolution-shaped product of the full-sequence
+// path is built from (see sequence.hip for the description), shared by sequence.hip
+// (decoder) and video.hip (video encoder / learned upsampler).
+#pragma once
+#include "common.h"
+
+namespace mvn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Act {  // (B, ch, ld) view
+  float *p;
+  long long sb;  // batch stride (floats)
+  int ld;        // row stride (floats)
+  __device__ __forceinline__ float *at(int b, int ch, int t) const {
+    return p + (size_t)b * sb + (size_t)ch * ld + t;
+  }
+};
+
+// accumulator register r of lane `lane` -> row inside a 32x32 MFMA tile
+__device__ __forceinline__ int acc_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// ======================================================================
+// gemm_wx: Y[m][t] = sum_k W(m,k) X(k,t), block tile 64(m) x 256(t),
+// 4 waves, wave w owns t in [64w, 64w+64) as 2x2 MFMA tiles.
+// ======================================================================
+constexpr int GX_KC = 16;  // k per LDS chunk
+
+template <class Op>
+__global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
+  __shared__ float Ws[2][GX_KC][64];
+  __shared__ float Xs[2][GX_KC][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, mb = blockIdx.y;
+  const int t0 = op.t_begin + blockIdx.x * 256;
+  const int nchunk = (op.K + GX_KC - 1) / GX_KC;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float wreg[4], xreg[16];
+  auto gload = [&](int c) {
+    const int k0 = c * GX_KC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + (tid & 63), k0 + (tid >> 6) + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xreg[j] = op.x(b, k0 + j, t0 + tid);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ws[buf][(tid >> 6) + 4 * j][tid & 63] = wreg[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Xs[buf][j][tid] = xreg[j];
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < GX_KC / 2; ++kk) {
+      const int kr = 2 * kk + (lane >> 5);
+      const float a0 = Ws[buf][kr][lane & 31], a1 = Ws[buf][kr][32 + (lane & 31)];
+      const float b0 = Xs[buf][kr][64 * wave + (lane & 31)];
+      const float b1 = Xs[buf][kr][64 * wave + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: acc[mi][ni][r] is row 32*mi + acc_row(r), column 64*wave + 32*ni + (lane&31)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int t = t0 + 64 * wave + 32 * ni + (lane & 31);
+    if (t < op.t_end) op.epilogue(b, mb, t, lane, acc[0][ni], acc[1][ni]);
+  }
+}
+
+// ======================================================================
+// wgrad: dW(m,n) += sum_{b,t} A(b,m,t) * X(b,n,t); block tile 64 x 64, each
+// wave one 32x32 MFMA tile, K = time.  Grid: (time chunks * B, M/64 * N/64).
+// ======================================================================
+constexpr int WG_T = 64;       // time per LDS tile
+constexpr int WG_CHUNK = 512;  // time per workgroup (8 tiles): >= 900 workgroups at config 2
+
+// bias_part: optional scratch [gridDim.x][64 * (M blocks)] -- every workgroup with
+// nblk == 0 stores its 64 row sums there and bias_reduce_kernel adds them up in a
+// fixed order.  (Atomics straight into the 64..256 bias words serialise: ~800
+// workgroups on four cache lines made this kernel 3x slower.)
+template <class Op>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int chunks_per_b,
+                                                      float *__restrict__ bias_part, int m_rows64) {
+  __shared__ float As[2][64][WG_T + 1];
+  __shared__ float Xs[2][64][WG_T + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
+  const int mi = wave >> 1, ni = wave & 1;
+  const int tb = op.t_begin + ch * WG_CHUNK, te = min(op.t_end, tb + WG_CHUNK);
+  const bool want_bias = nblk == 0;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // wave w stages rows w, w+4, ..., w+60 (lane = time): 16 + 16 values per thread
+  float areg[16], xreg[16], bsum[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
+  auto gload = [&](int t0) {
+    const int t = t0 + lane;
+    const bool ok = t < te;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = wave + 4 * j;
+      areg[j] = ok ? op.a(b, mblk * 64 + row, t) : 0.f;
+      xreg[j] = ok ? op.x(b, nblk * 64 + row, t) : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      As[buf][wave + 4 * j][lane] = areg[j];
+      Xs[buf][wave + 4 * j][lane] = xreg[j];
+      bsum[j] += areg[j];  // bias gradient = row sums of A, folded into the staging pass
+    }
+  };
+
+  gload(tb);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int t0 = tb; t0 < te; t0 += WG_T, buf ^= 1) {
+    const bool more = t0 + WG_T < te;
+    if (more) gload(t0 + WG_T);  // next tile's global loads fly under this tile's MFMAs
+#pragma unroll 8
+    for (int kk = 0; kk < WG_T / 2; ++kk) {
+      const int tc = 2 * kk + (lane >> 5);
+      const float av = As[buf][32 * mi + (lane & 31)][tc];
+      const float xv = Xs[buf][32 * ni + (lane & 31)][tc];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mblk * 64 + 32 * mi + acc_row(r, lane), n = nblk * 64 + 32 * ni + (lane & 31);
+    float *dst = op.dw(m, n);
+    if (dst) atomicAdd(dst, acc[r]);
+  }
+  if (want_bias) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float v = wave_sum(bsum[j]);
+      const int m = mblk * 64 + wave + 4 * j;
+      if (lane == 0) {
+        if (bias_part) {
+          bias_part[(size_t)blockIdx.x * m_rows64 + m] = v;
+        } else {  // scratch too small for this shape: contended but correct
+          float *dst = op.db(m);
+          if (dst) atomicAdd(dst, v);
+        }
+      }
+    }
+  }
+}
+
+// one wave per bias word: lane-strided partial sums in a fixed order, then a wave sum
+template <class Op>
+__global__ void bias_reduce_kernel(Op op, const float *__restrict__ bias_part, int nparts,
+                                   int m_rows64) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  float *dst = op.db(m);
+  if (!dst) return;
+  float s = 0.f;
+  for (int p = lane; p < nparts; p += 64) s += bias_part[(size_t)p * m_rows64 + m];
+  s = wave_sum(s);
+  if (lane == 0) atomicAdd(dst, s);  // rows may share a word (transposed-conv taps)
+}
+
+static Act act_view(float *p, int batch, int ch, int ld) {
+  Act a;
+  a.p = p;
+  a.sb = (long long)ch * ld;
+  a.ld = ld;
+  return a;
+}
+
+template <class Op>
+static void launch_gemm(const Op &op, int m_rows, int batch, hipStream_t s) {
+  const int nt = op.t_end - op.t_begin;
+  if (nt <= 0 || batch <= 0) return;
+  dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
+  hipLaunchKernelGGL(gemm_wx_kernel<Op>, grid, dim3(256), 0, s, op);
+}
+
+// bias_scratch: >= chunks*batch*64*ceil(m_rows/64) floats, or NULL when the op has no bias
+template <class Op>
+static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, float *bias_scratch,
+                         hipStream_t s) {
+  const int nt = op.t_end - op.t_begin;
+  if (nt <= 0 || batch <= 0) return;
+  const int chunks = (nt + WG_CHUNK - 1) / WG_CHUNK;
+  const int mb = (m_rows + 63) / 64, nb = (n_rows + 63) / 64;
+  dim3 grid(chunks * batch, mb * nb);
+  hipLaunchKernelGGL(wgrad_kernel<Op>, grid, dim3(256), 0, s, op, nb, chunks, bias_scratch, mb * 64);
+  if (bias_scratch)
+    hipLaunchKernelGGL(bias_reduce_kernel<Op>, dim3(mb * 64), dim3(64), 0, s, op, bias_scratch,
+                       chunks * batch, mb * 64);
+}
+
+
+}  // namespace mvn

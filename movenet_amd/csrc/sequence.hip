@@ -18,109 +18,36 @@
 // Activations use an ABSOLUTE time axis (see movenet_hip.h): tensor (B, ch, Tp),
 // column t = input time t, layer l's input valid for t >= A_l.
 #include "common.h"
+#include "gemm_family.h"
 
 namespace mvn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct Act {  // (B, ch, ld) view
-  float *p;
-  long long sb;  // batch stride (floats)
-  int ld;        // row stride (floats)
-  __device__ __forceinline__ float *at(int b, int ch, int t) const {
-    return p + (size_t)b * sb + (size_t)ch * ld + t;
-  }
-};
-
-// accumulator register r of lane `lane` -> row inside a 32x32 MFMA tile
-__device__ __forceinline__ int acc_row(int r, int lane) {
-  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-}
-
-// ======================================================================
-// gemm_wx: Y[m][t] = sum_k W(m,k) X(k,t), block tile 64(m) x 256(t),
-// 4 waves, wave w owns t in [64w, 64w+64) as 2x2 MFMA tiles.
-// ======================================================================
-constexpr int GX_KC = 16;  // k per LDS chunk
-
-template <class Op>
-__global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
-  __shared__ float Ws[2][GX_KC][64];
-  __shared__ float Xs[2][GX_KC][256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, mb = blockIdx.y;
-  const int t0 = op.t_begin + blockIdx.x * 256;
-  const int nchunk = (op.K + GX_KC - 1) / GX_KC;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float wreg[4], xreg[16];
-  auto gload = [&](int c) {
-    const int k0 = c * GX_KC;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + (tid & 63), k0 + (tid >> 6) + 4 * j);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xreg[j] = op.x(b, k0 + j, t0 + tid);
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Ws[buf][(tid >> 6) + 4 * j][tid & 63] = wreg[j];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) Xs[buf][j][tid] = xreg[j];
-  };
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) gload(c + 1);
-#pragma unroll
-    for (int kk = 0; kk < GX_KC / 2; ++kk) {
-      const int kr = 2 * kk + (lane >> 5);
-      const float a0 = Ws[buf][kr][lane & 31], a1 = Ws[buf][kr][32 + (lane & 31)];
-      const float b0 = Xs[buf][kr][64 * wave + (lane & 31)];
-      const float b1 = Xs[buf][kr][64 * wave + 32 + (lane & 31)];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (c + 1 < nchunk) lstore(buf ^ 1);
-    __syncthreads();
-  }
-  // epilogue: acc[mi][ni][r] is row 32*mi + acc_row(r), column 64*wave + 32*ni + (lane&31)
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int t = t0 + 64 * wave + 32 * ni + (lane & 31);
-    if (t < op.t_end) op.epilogue(b, mb, t, lane, acc[0][ni], acc[1][ni]);
-  }
-}
 
 // ---- forward ops -------------------------------------------------------
 // F1: f,g = dilated k=2 conv, z = tanh(f)*sigmoid(g).  Row block mb covers
 // channels [32mb, 32mb+32): tile rows 0..31 = filter rows, 32..63 = gate rows,
 // so a lane holds f and g of the same (channel, t) in matching registers.
+// With local conditioning (ctx.p != NULL) K grows to 3C: columns [2C,3C) are the 1x1
+// context convolutions (modules.py:58-63, :75-77), their biases are added in the epilogue.
+// BUILD DEFINITION: the context is aligned on the same absolute time as f/g (the
+// reference raises a shape error here).
 struct FgOp {
   int K, t_begin, t_end, C, d;
   const float *wf, *wg;  // (C, C, 2)
+  const float *wcf, *wcg, *bcf, *bcg;  // (C, C, 1), (C)
   Act xin;               // layer input
+  Act ctx;               // upsampled video or p == NULL
   Act z, th, sg;         // outputs (th/sg.p may be NULL)
   __device__ __forceinline__ float w(int m, int k) const {
     const int r = m & 63, c = (m >> 6) * 32 + (r & 31);
+    if (c >= C || k >= K) return 0.f;
+    if (k >= 2 * C) return (r < 32 ? wcf : wcg)[(size_t)c * C + (k - 2 * C)];
     const int tap = k >= C, kc = k - tap * C;
-    if (c >= C || k >= 2 * C) return 0.f;
     const float *src = r < 32 ? wf : wg;
     return src[((size_t)c * C + kc) * 2 + tap];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    if (k >= 2 * C || t >= t_end) return 0.f;
+    if (k >= K || t >= t_end) return 0.f;
+    if (k >= 2 * C) return *ctx.at(b, k - 2 * C, t);
     return k < C ? *xin.at(b, k, t - d) : *xin.at(b, k - C, t);  // t >= t_begin >= d
   }
   __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &f,
@@ -129,7 +56,12 @@ struct FgOp {
     for (int r = 0; r < 16; ++r) {
       const int c = mb * 32 + acc_row(r, lane);
       if (c < C) {
-        const float tv = tanhf(f[r]), sv = 1.0f / (1.0f + expf(-g[r]));
+        float fv = f[r], gv = g[r];
+        if (ctx.p) {
+          fv += bcf[c];
+          gv += bcg[c];
+        }
+        const float tv = tanhf(fv), sv = 1.0f / (1.0f + expf(-gv));
         *z.at(b, c, t) = tv * sv;
         if (th.p) {
           *th.at(b, c, t) = tv;
@@ -321,127 +253,56 @@ struct DxOp {
   }
 };
 
-// ======================================================================
-// wgrad: dW(m,n) += sum_{b,t} A(b,m,t) * X(b,n,t); block tile 64 x 64, each
-// wave one 32x32 MFMA tile, K = time.  Grid: (time chunks * B, M/64 * N/64).
-// ======================================================================
-constexpr int WG_T = 64;       // time per LDS tile
-constexpr int WG_CHUNK = 512;  // time per workgroup (8 tiles): >= 900 workgroups at config 2
-
-// bias_part: optional scratch [gridDim.x][64 * (M blocks)] -- every workgroup with
-// nblk == 0 stores its 64 row sums there and bias_reduce_kernel adds them up in a
-// fixed order.  (Atomics straight into the 64..256 bias words serialise: ~800
-// workgroups on four cache lines made this kernel 3x slower.)
-template <class Op>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int chunks_per_b,
-                                                      float *__restrict__ bias_part, int m_rows64) {
-  __shared__ float As[2][64][WG_T + 1];
-  __shared__ float Xs[2][64][WG_T + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
-  const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
-  const int mi = wave >> 1, ni = wave & 1;
-  const int tb = op.t_begin + ch * WG_CHUNK, te = min(op.t_end, tb + WG_CHUNK);
-  const bool want_bias = nblk == 0;
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // wave w stages rows w, w+4, ..., w+60 (lane = time): 16 + 16 values per thread
-  float areg[16], xreg[16], bsum[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
-  auto gload = [&](int t0) {
-    const int t = t0 + lane;
-    const bool ok = t < te;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = wave + 4 * j;
-      areg[j] = ok ? op.a(b, mblk * 64 + row, t) : 0.f;
-      xreg[j] = ok ? op.x(b, nblk * 64 + row, t) : 0.f;
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      As[buf][wave + 4 * j][lane] = areg[j];
-      Xs[buf][wave + 4 * j][lane] = xreg[j];
-      bsum[j] += areg[j];  // bias gradient = row sums of A, folded into the staging pass
-    }
-  };
-
-  gload(tb);
-  lstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int t0 = tb; t0 < te; t0 += WG_T, buf ^= 1) {
-    const bool more = t0 + WG_T < te;
-    if (more) gload(t0 + WG_T);  // next tile's global loads fly under this tile's MFMAs
-#pragma unroll 8
-    for (int kk = 0; kk < WG_T / 2; ++kk) {
-      const int tc = 2 * kk + (lane >> 5);
-      const float av = As[buf][32 * mi + (lane & 31)][tc];
-      const float xv = Xs[buf][32 * ni + (lane & 31)][tc];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
-    }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = mblk * 64 + 32 * mi + acc_row(r, lane), n = nblk * 64 + 32 * ni + (lane & 31);
-    float *dst = op.dw(m, n);
-    if (dst) atomicAdd(dst, acc[r]);
-  }
-  if (want_bias) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float v = wave_sum(bsum[j]);
-      const int m = mblk * 64 + wave + 4 * j;
-      if (lane == 0) {
-        if (bias_part) {
-          bias_part[(size_t)blockIdx.x * m_rows64 + m] = v;
-        } else {  // scratch too small for this shape: contended but correct
-          float *dst = op.db(m);
-          if (dst) atomicAdd(dst, v);
-        }
-      }
-    }
-  }
-}
-
-// one wave per bias word: lane-strided partial sums in a fixed order, then a wave sum
-template <class Op>
-__global__ void bias_reduce_kernel(Op op, const float *__restrict__ bias_part, int nparts,
-                                   int m_rows64) {
-  const int m = blockIdx.x, lane = threadIdx.x;
-  float *dst = op.db(m);
-  if (!dst) return;
-  float s = 0.f;
-  for (int p = lane; p < nparts; p += 64) s += bias_part[(size_t)p * m_rows64 + m];
-  s = wave_sum(s);
-  if (lane == 0) *dst += s;
-}
-
 // dWf/dWg: A = dfg rows (f | g), X = layer input (past | cur) -> (C,C,2) taps
 struct WgFgOp {
   int t_begin, t_end, C, d;
-  Act dfg, xin;
-  float *dwf, *dwg;
+  Act dfg, xin, ctx;  // ctx.p == NULL: audio only
+  float *dwf, *dwg, *dwcf, *dwcg, *dbcf, *dbcg;
   __device__ __forceinline__ float a(int b, int m, int t) const {
     return m < 2 * C ? *dfg.at(b, m, t) : 0.f;
   }
   __device__ __forceinline__ float x(int b, int n, int t) const {
-    if (n >= 2 * C) return 0.f;
+    if (n >= 2 * C) return (ctx.p && n < 3 * C) ? *ctx.at(b, n - 2 * C, t) : 0.f;
     return n < C ? *xin.at(b, n, t - d) : *xin.at(b, n - C, t);
   }
   __device__ __forceinline__ float *dw(int m, int n) const {
-    if (m >= 2 * C || n >= 2 * C) return nullptr;
+    if (m >= 2 * C) return nullptr;
+    const int o = m < C ? m : m - C;
+    if (n >= 2 * C) {
+      if (!ctx.p || n >= 3 * C) return nullptr;
+      return (m < C ? dwcf : dwcg) + (size_t)o * C + (n - 2 * C);
+    }
     float *base = m < C ? dwf : dwg;
-    const int o = m < C ? m : m - C, tap = n >= C, c = n - tap * C;
+    const int tap = n >= C, c = n - tap * C;
     return base + ((size_t)o * C + c) * 2 + tap;
   }
-  __device__ __forceinline__ float *db(int m) const { return nullptr; }
+  __device__ __forceinline__ float *db(int m) const {
+    if (!ctx.p || m >= 2 * C) return nullptr;
+    return m < C ? dbcf + m : dbcg + (m - C);
+  }
+};
+
+// gradient w.r.t. the context: dctx[t] += Wcf^T df[t] + Wcg^T dg[t]   (t >= t_lo)
+struct DctxOp {
+  int K, t_begin, t_end, C;
+  const float *wcf, *wcg;
+  Act dfg, dctx;
+  __device__ __forceinline__ float w(int m, int k) const {
+    if (m >= C || k >= 2 * C) return 0.f;
+    return k < C ? wcf[(size_t)k * C + m] : wcg[(size_t)(k - C) * C + m];
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    return (k < 2 * C && t < t_end) ? *dfg.at(b, k, t) : 0.f;
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
+                                           const f32x16 &a1) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m0 = mb * 64 + acc_row(r, lane), m1 = m0 + 32;
+      if (m0 < C) *dctx.at(b, m0, t) += a0[r];
+      if (m1 < C) *dctx.at(b, m1, t) += a1[r];
+    }
+  }
 };
 
 // dWr,dbr,dWs,dbs: A = [dxo ; dskip], X = z = th*sg
@@ -609,37 +470,6 @@ static int make_geometry(const mvn_dims *d, int batch, int t_len, Geometry &g) {
   return MVN_OK;
 }
 
-static Act act_view(float *p, int batch, int ch, int ld) {
-  Act a;
-  a.p = p;
-  a.sb = (long long)ch * ld;
-  a.ld = ld;
-  return a;
-}
-
-template <class Op>
-static void launch_gemm(const Op &op, int m_rows, int batch, hipStream_t s) {
-  const int nt = op.t_end - op.t_begin;
-  if (nt <= 0 || batch <= 0) return;
-  dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
-  hipLaunchKernelGGL(gemm_wx_kernel<Op>, grid, dim3(256), 0, s, op);
-}
-
-// bias_scratch: >= chunks*batch*64*ceil(m_rows/64) floats, or NULL when the op has no bias
-template <class Op>
-static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, float *bias_scratch,
-                         hipStream_t s) {
-  const int nt = op.t_end - op.t_begin;
-  if (nt <= 0 || batch <= 0) return;
-  const int chunks = (nt + WG_CHUNK - 1) / WG_CHUNK;
-  const int mb = (m_rows + 63) / 64, nb = (n_rows + 63) / 64;
-  dim3 grid(chunks * batch, mb * nb);
-  hipLaunchKernelGGL(wgrad_kernel<Op>, grid, dim3(256), 0, s, op, nb, chunks, bias_scratch, mb * 64);
-  if (bias_scratch)
-    hipLaunchKernelGGL(bias_reduce_kernel<Op>, dim3(mb * 64), dim3(64), 0, s, op, bias_scratch,
-                       chunks * batch, mb * 64);
-}
-
 }  // namespace mvn
 
 using namespace mvn;
@@ -674,6 +504,13 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
                      index, index_stride, x0, C, Q, T);
   Act zv = act_view(buf->z, batch, C, g.Tp);
   Act skipv = act_view(buf->skip, batch, Kc, g.Sp);
+  const bool has_ctx = buf->ctx != nullptr;
+  if (has_ctx && (!p->ctx_filter_w || !p->ctx_filter_b || !p->ctx_gate_w || !p->ctx_gate_b ||
+                  buf->ctx_ld < T)) {
+    set_error("mvn_forward: context given without context-conv parameters / ctx_ld < t_len");
+    return MVN_ERR_BAD_ARG;
+  }
+  Act ctxv = act_view(const_cast<float *>(buf->ctx), batch, C, has_ctx ? buf->ctx_ld : 0);
   int A = 0;  // first valid time of the current layer's input
   for (int l = 0; l < g.L; ++l) {
     const int d = dilation_of(dims, l);
@@ -681,8 +518,11 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     Act xin = act_view(buf->acts + (size_t)src * g.act, batch, C, g.Tp);
     Act xout = act_view(buf->acts + (size_t)dst * g.act, batch, C, g.Tp);
     FgOp f;
-    f.K = 2 * C; f.t_begin = A + d; f.t_end = T; f.C = C; f.d = d;
+    f.K = has_ctx ? 3 * C : 2 * C; f.t_begin = A + d; f.t_end = T; f.C = C; f.d = d;
     f.wf = p->filter_w[l]; f.wg = p->gate_w[l];
+    f.wcf = has_ctx ? p->ctx_filter_w[l] : nullptr; f.wcg = has_ctx ? p->ctx_gate_w[l] : nullptr;
+    f.bcf = has_ctx ? p->ctx_filter_b[l] : nullptr; f.bcg = has_ctx ? p->ctx_gate_b[l] : nullptr;
+    f.ctx = ctxv;
     f.xin = xin; f.z = zv;
     f.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
     f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
@@ -780,6 +620,24 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       if (l < g.L) A += dilation_of(dims, l);
     }
   }
+  const bool has_ctx = fwd->ctx != nullptr;
+  if (has_ctx && (!bwd->dctx || !gr->ctx_filter_w || !gr->ctx_filter_b || !gr->ctx_gate_w ||
+                  !gr->ctx_gate_b || !p->ctx_filter_w || !p->ctx_gate_w)) {
+    set_error("mvn_backward: context given without dctx buffer / context-conv gradients");
+    return MVN_ERR_BAD_ARG;
+  }
+  Act ctxv = act_view(const_cast<float *>(fwd->ctx), batch, C, has_ctx ? fwd->ctx_ld : 0);
+  Act dctxv = act_view(bwd->dctx, batch, C, g.Tp);
+  if (has_ctx) {
+    rc = check_hip(hipMemsetAsync(bwd->dctx, 0, sizeof(float) * (size_t)g.act, s), "memset dctx");
+    if (rc) return rc;
+  }
+  // bias partials of the context convs: dfg is busy while WgFgOp runs, use dlogit
+  float *ctx_bias_scratch = bwd->dlogit;
+  {
+    const size_t need = (size_t)((T + WG_CHUNK - 1) / WG_CHUNK) * batch * ((2 * C + 63) / 64 * 64);
+    if (need > (size_t)g.hid) ctx_bias_scratch = nullptr;
+  }
   float *dxo_p = nullptr;  // gradient w.r.t. the layer's residual output
   float *cur = bwd->dx_a, *nxt = bwd->dx_b;
   Act dfg = act_view(bwd->dfg, batch, 2 * C, g.Tp);
@@ -802,9 +660,17 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     dz.dxo = dxo; dz.dskip = dskip; dz.th = th; dz.sg = sg; dz.dfg = dfg;
     launch_gemm(dz, C, batch, s);
     WgFgOp wf;
-    wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin;
+    wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
     wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
-    launch_wgrad(wf, 2 * C, 2 * C, batch, nullptr, s);
+    wf.dwcf = has_ctx ? gr->ctx_filter_w[l] : nullptr; wf.dwcg = has_ctx ? gr->ctx_gate_w[l] : nullptr;
+    wf.dbcf = has_ctx ? gr->ctx_filter_b[l] : nullptr; wf.dbcg = has_ctx ? gr->ctx_gate_b[l] : nullptr;
+    launch_wgrad(wf, 2 * C, has_ctx ? 3 * C : 2 * C, batch, has_ctx ? ctx_bias_scratch : nullptr, s);
+    if (has_ctx) {
+      DctxOp dc;
+      dc.K = 2 * C; dc.t_begin = t_lo; dc.t_end = T; dc.C = C;
+      dc.wcf = p->ctx_filter_w[l]; dc.wcg = p->ctx_gate_w[l]; dc.dfg = dfg; dc.dctx = dctxv;
+      launch_gemm(dc, C, batch, s);
+    }
     DxOp dx;
     dx.K = 4 * C; dx.t_begin = A_lo[l]; dx.t_end = T; dx.C = C; dx.d = d; dx.t_lo = t_lo;
     dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];

@@ -10,20 +10,31 @@ from __future__ import annotations
 
 from typing import Dict, List, Tuple
 
+import ctypes
+
 import torch
 
 from . import _native as N
 from .generation import _require_gpu, _stream_ptr, pack_params
 
+C_void3 = ctypes.c_void_p * 3
+
 _LAYER_PARAMS = ("conv_filter.conv.weight", "conv_gate.conv.weight", "conv_residual.weight",
                  "conv_residual.bias", "conv_skip.weight", "conv_skip.bias")
+_CTX_PARAMS = ("context_conv_filter.weight", "context_conv_filter.bias",
+               "context_conv_gate.weight", "context_conv_gate.bias")
+VIDEO_PARAMS = ("video_conv.weight", "video_conv.bias",
+                "video_transpose.0.weight", "video_transpose.0.bias",
+                "video_transpose.1.weight", "video_transpose.1.bias",
+                "video_transpose.2.weight", "video_transpose.2.bias")
 
 
-def decoder_param_names(n_layers: int) -> List[str]:
-    """Parameters the audio path uses, in the order they are passed to autograd."""
+def decoder_param_names(n_layers: int, with_context: bool = False) -> List[str]:
+    """Parameters the decoder uses, in the order they are passed to autograd."""
+    per_layer = _LAYER_PARAMS + (_CTX_PARAMS if with_context else ())
     names = ["causal_conv.conv.weight"]
     for l in range(n_layers):
-        names += [f"residual_conv_stack.conv_layers.{l}.{p}" for p in _LAYER_PARAMS]
+        names += [f"residual_conv_stack.conv_layers.{l}.{p}" for p in per_layer]
     names += ["dense_conv.conv1.weight", "dense_conv.conv1.bias",
               "dense_conv.conv2.weight", "dense_conv.conv2.bias"]
     return names
@@ -32,7 +43,7 @@ def decoder_param_names(n_layers: int) -> List[str]:
 class ForwardBuffers:
     """Device buffers of one forward pass (sizes: include/movenet_hip.h)."""
 
-    def __init__(self, dims: N.Dims, batch: int, t_len: int, save: bool, device):
+    def __init__(self, dims: N.Dims, batch: int, t_len: int, save: bool, device, ctx=None):
         lib = N.lib()
         L = dims.layer_size * dims.stack_size
         C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
@@ -45,21 +56,29 @@ class ForwardBuffers:
         self.z = torch.empty((batch, C, self.Tp), **f32)
         self.skip = torch.empty((batch, K, self.Sp), **f32)
         self.a1 = torch.empty((batch, Q, self.Sp), **f32)
+        self.ctx = ctx
         self.struct = N.FwdBuffers(
             self.acts.data_ptr(), self.th.data_ptr() if save else None,
             self.sg.data_ptr() if save else None, self.z.data_ptr(), self.skip.data_ptr(),
-            self.a1.data_ptr())
+            self.a1.data_ptr(), None if ctx is None else ctx.data_ptr(),
+            0 if ctx is None else ctx.stride(1))
 
 
 def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, normalize: bool,
-                remove_last: bool, save: bool) -> Tuple[torch.Tensor, ForwardBuffers]:
+                remove_last: bool, save: bool, ctx=None) -> Tuple[torch.Tensor, ForwardBuffers]:
     lib = N.lib()
     _require_gpu(idx, "audio indices")
     B, T = idx.shape
     L = dims.layer_size * dims.stack_size
     dev = idx.device
+    if ctx is not None:
+        # same check as the reference's assert (wavenet.py:170-174)
+        assert tuple(ctx.shape) == (B, dims.residual_channels, T), (
+            "expected video and audio tensors to have equal sizes, found "
+            f"{tuple(ctx.shape)}, {(B, dims.residual_channels, T)}")
+        ctx = ctx.detach().to(torch.float32).contiguous()
     with torch.cuda.device(dev):
-        buf = ForwardBuffers(dims, B, T, save, dev)
+        buf = ForwardBuffers(dims, B, T, save, dev, ctx)
         s_out = buf.S - (1 if remove_last else 0)
         out = torch.empty((B, dims.input_channels, max(s_out, 0)), dtype=torch.float32, device=dev)
         params, keep = pack_params(dims, sd, L)
@@ -71,23 +90,27 @@ def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, no
 
 
 class _WaveNetFunction(torch.autograd.Function):
+    """args: dims, names, idx, normalize, remove_last, ctx (Tensor or None), *params"""
+    N_FIXED = 6
+
     @staticmethod
-    def forward(ctx, dims, names, idx, normalize, remove_last, *params):
+    def forward(ctx_, dims, names, idx, normalize, remove_last, context, *params):
         sd = dict(zip(names, params))
-        save = any(ctx.needs_input_grad[5:])  # grad mode itself is off inside forward()
-        out, buf = run_forward(dims, sd, idx, normalize, remove_last, save)
-        ctx.dims, ctx.names, ctx.idx, ctx.buf = dims, names, idx, buf
-        ctx.normalize, ctx.remove_last, ctx.saved_fwd = normalize, remove_last, save
-        ctx.save_for_backward(out, *params)
+        save = any(ctx_.needs_input_grad[5:])  # grad mode itself is off inside forward()
+        out, buf = run_forward(dims, sd, idx, normalize, remove_last, save, context)
+        ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf = dims, names, idx, buf
+        ctx_.normalize, ctx_.remove_last, ctx_.saved_fwd = normalize, remove_last, save
+        ctx_.has_context = context is not None
+        ctx_.save_for_backward(out, *params)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        if not ctx.saved_fwd:
+    def backward(ctx_, dout):
+        if not ctx_.saved_fwd:
             raise RuntimeError("movenet_amd: forward ran without saved activations")
         lib = N.lib()
-        out, *params = ctx.saved_tensors
-        dims, names, idx, buf = ctx.dims, ctx.names, ctx.idx, ctx.buf
+        out, *params = ctx_.saved_tensors
+        dims, names, idx, buf = ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf
         L = dims.layer_size * dims.stack_size
         C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
         B, T = idx.shape
@@ -98,7 +121,8 @@ class _WaveNetFunction(torch.autograd.Function):
             grads = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in sd.items()}
             gp, gkeep = pack_params(dims, grads, L)
             g = N.ParamGrads(gp.causal_w, gp.filter_w, gp.gate_w, gp.residual_w, gp.residual_b,
-                             gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b)
+                             gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b,
+                             gp.ctx_filter_w, gp.ctx_filter_b, gp.ctx_gate_w, gp.ctx_gate_b)
             f32 = dict(dtype=torch.float32, device=dev)
             dx_a = torch.empty((B, C, buf.Tp), **f32)
             dx_b = torch.empty((B, C, buf.Tp), **f32)
@@ -106,33 +130,99 @@ class _WaveNetFunction(torch.autograd.Function):
             dskip = torch.empty((B, K, buf.Sp), **f32)
             da1 = torch.empty((B, Q, buf.Sp), **f32)
             dlogit = torch.empty((B, Q, buf.Sp), **f32)
+            dctx = torch.empty((B, C, buf.Tp), **f32) if ctx_.has_context else None
             bw = N.BwdBuffers(dx_a.data_ptr(), dx_b.data_ptr(), dfg.data_ptr(), dskip.data_ptr(),
-                              da1.data_ptr(), dlogit.data_ptr())
+                              da1.data_ptr(), dlogit.data_ptr(),
+                              None if dctx is None else dctx.data_ptr())
             params_c, pkeep = pack_params(dims, sd, L)
             N.check(lib.mvn_backward(dims, params_c, g, idx.data_ptr(), idx.stride(0), B, T,
                                      buf.struct, bw, out.data_ptr(), dout.data_ptr(),
-                                     int(ctx.normalize), int(ctx.remove_last), _stream_ptr(dev)),
+                                     int(ctx_.normalize), int(ctx_.remove_last), _stream_ptr(dev)),
                     "mvn_backward")
-        ctx.buf = None
+        ctx_.buf = None
         last = f"residual_conv_stack.conv_layers.{L - 1}.conv_residual."
+        need = ctx_.needs_input_grad
         result = []
-        for n, need in zip(names, ctx.needs_input_grad[5:]):
+        for n, want in zip(names, need[_WaveNetFunction.N_FIXED:]):
             # the last layer's residual conv never reaches the output: the
             # reference leaves its .grad None, so do we
-            result.append(None if (n.startswith(last) or not need) else grads[n])
-        return (None, None, None, None, None, *result)
+            result.append(None if (n.startswith(last) or not want) else grads[n])
+        dcontext = dctx[:, :, :T] if (ctx_.has_context and need[5]) else None
+        return (None, None, None, None, None, dcontext, *result)
 
 
-def wavenet_forward(model, audio: torch.Tensor, output_unnormalized: bool = True,
+class _UpsampleVideoFunction(torch.autograd.Function):
+    """video (B,F,64,64,Cin) -> context (B,C,1000F) through mvn_upsample_video."""
+
+    @staticmethod
+    def forward(ctx_, dims, video, *params):
+        lib = N.lib()
+        _require_gpu(video, "video")
+        if video.dim() != 5 or video.shape[2] != 64 or video.shape[3] != 64:
+            raise ValueError(f"video must be (batch, frames, 64, 64, channels), got {tuple(video.shape)}")
+        video = video.detach().to(torch.float32).contiguous()
+        B, F, _, _, cin = video.shape
+        C = dims.residual_channels
+        dev = video.device
+        pl = lib.mvn_padded_len
+        with torch.cuda.device(dev):
+            f32 = dict(dtype=torch.float32, device=dev)
+            enc = torch.empty((B, C, pl(F)), **f32)
+            u1 = torch.empty((B, C, pl(10 * F)), **f32)
+            u2 = torch.empty((B, C, pl(100 * F)), **f32)
+            out = torch.empty((B, C, 1000 * F), **f32)
+            ps = [p.detach().to(torch.float32).contiguous() for p in params]
+            vp = N.VideoParams(ps[0].data_ptr(), ps[1].data_ptr(),
+                               (C_void3)(ps[2].data_ptr(), ps[4].data_ptr(), ps[6].data_ptr()),
+                               (C_void3)(ps[3].data_ptr(), ps[5].data_ptr(), ps[7].data_ptr()))
+            N.check(lib.mvn_upsample_video(dims, vp, video.data_ptr(), B, F, cin, enc.data_ptr(),
+                                           u1.data_ptr(), u2.data_ptr(), out.data_ptr(),
+                                           out.stride(1), _stream_ptr(dev)), "mvn_upsample_video")
+        ctx_.dims, ctx_.shape = dims, (B, F, cin)
+        ctx_.save_for_backward(video, enc, u1, u2, *ps)
+        return out
+
+    @staticmethod
+    def backward(ctx_, dout):
+        lib = N.lib()
+        video, enc, u1, u2, *ps = ctx_.saved_tensors
+        dims = ctx_.dims
+        B, F, cin = ctx_.shape
+        dev = video.device
+        dout = dout.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            grads = [torch.zeros_like(p) for p in ps]
+            vp = N.VideoParams(ps[0].data_ptr(), ps[1].data_ptr(),
+                               (C_void3)(ps[2].data_ptr(), ps[4].data_ptr(), ps[6].data_ptr()),
+                               (C_void3)(ps[3].data_ptr(), ps[5].data_ptr(), ps[7].data_ptr()))
+            vg = N.VideoParams(grads[0].data_ptr(), grads[1].data_ptr(),
+                               (C_void3)(grads[2].data_ptr(), grads[4].data_ptr(), grads[6].data_ptr()),
+                               (C_void3)(grads[3].data_ptr(), grads[5].data_ptr(), grads[7].data_ptr()))
+            d_u2, d_u1, d_enc = torch.empty_like(u2), torch.empty_like(u1), torch.empty_like(enc)
+            N.check(lib.mvn_upsample_video_backward(
+                dims, vp, vg, video.data_ptr(), B, F, cin, enc.data_ptr(), u1.data_ptr(),
+                u2.data_ptr(), dout.data_ptr(), dout.stride(1), d_u2.data_ptr(), d_u1.data_ptr(),
+                d_enc.data_ptr(), _stream_ptr(dev)), "mvn_upsample_video_backward")
+        need = ctx_.needs_input_grad[2:]
+        return (None, None, *[g if w else None for g, w in zip(grads, need)])
+
+
+def upsample_video(model, video: torch.Tensor) -> torch.Tensor:
+    lookup = dict(model.named_parameters())
+    return _UpsampleVideoFunction.apply(model._dims, video, *[lookup[n] for n in VIDEO_PARAMS])
+
+
+def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalized: bool = True,
                     remove_last: bool = True) -> torch.Tensor:
-    """WaveNet.forward for the audio-only path.  NOTE the reference's inverted
-    flag (wavenet.py:189-191): output_unnormalized=True returns PROBABILITIES."""
+    """WaveNet.forward.  NOTE the reference's inverted flag (wavenet.py:189-191):
+    output_unnormalized=True returns PROBABILITIES.  ``context``: upsampled video
+    (B, C, T) or None."""
     idx = model._indices_of(audio)
     model.compute_output_size(audio)  # ValueError when T < RF, like the reference
     L = model.layer_size * model.stack_size
-    names = decoder_param_names(L)
+    names = decoder_param_names(L, with_context=context is not None)
     lookup = dict(model.named_parameters())
     params = [lookup[n] for n in names]
     out = _WaveNetFunction.apply(model._dims, names, idx, bool(output_unnormalized),
-                                 bool(remove_last), *params)
+                                 bool(remove_last), context, *params)
     return out if audio.dtype == torch.float32 else out.to(audio.dtype)

@@ -150,17 +150,21 @@ class WaveNet(nn.Module):
 
     # ---- model API ------------------------------------------------------
     def upsample_video(self, video):
-        raise NotImplementedError(
-            "video conditioning (SURVEY.md section 8f, row F1) is not built yet")
+        """(B, F, 64, 64, Cin) -> (B, C, 1000 F): wavenet.py:149-156 (pinned by fixture G7)."""
+        from .ops import upsample_video
+        out = upsample_video(self, video)
+        assert out.shape[-1] == MAX_AUDIO_FRAMES  # same assert as the reference (:155)
+        return out
 
     def forward(self, audio, video=None, global_features=None, output_unnormalized: bool = True,
                 remove_last: bool = True):
+        """BUILD DEFINITION for video != None: the reference raises a shape error at
+        modules.py:75-77; here the upsampled video is added to the filter
+        and gate pre-activations at the same absolute time (right-aligned, like the
+        residual input at modules.py:84)."""
         from .ops import wavenet_forward  # HIP full-sequence kernels
-        if video is not None:
-            raise NotImplementedError(
-                "the video-conditioned forward raises in the reference itself "
-                "(SURVEY.md Q6); conditioning is a later row (section 8f F1)")
-        return wavenet_forward(self, audio, output_unnormalized=output_unnormalized,
+        context = None if video is None else self.upsample_video(video)
+        return wavenet_forward(self, audio, context, output_unnormalized=output_unnormalized,
                                remove_last=remove_last)
 
     @torch.no_grad()

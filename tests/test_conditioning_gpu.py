@@ -1,0 +1,92 @@
+"""GPU: local conditioning (video encoder, learned upsampler, context convs).
+
+* ``upsample_video`` is PINNED: fixture G7 was recorded from the reference itself.
+* The conditioned gated layer is a BUILD DEFINITION (the reference raises there,
+  SURVEY.md Q6/Q7): these tests compare against this repo's oracle, whose context
+  alignment is the same definition -- parity with the reference is UNPINNED.
+Tolerances as in test_forward_gpu.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import one_hot, rel_err, synthetic_indices, weights_of
+from movenet_amd.utils.weights import make_state_dict
+from oracle import wavenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(cfg, sd):
+    from movenet_amd.wavenet import WaveNet
+    m = WaveNet(**cfg)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+def test_g7_upsample_video_pinned(golden):
+    fx = golden("g7_upsample_video.npz")
+    cfg, dims, sd = weights_of(fx)
+    rng = np.random.default_rng(int(fx["video_seed"]))
+    video = torch.from_numpy(rng.random((1, 160, 64, 64, 1), dtype=np.float32)).to(DEV)
+    with torch.no_grad():
+        up = _model(cfg, sd).upsample_video(video)
+    assert up.shape == (1, cfg["residual_channels"], 160000)
+    assert rel_err(up[:, :, torch.from_numpy(fx["cols"]).to(DEV)].cpu(), fx["up_cols"]) < 1e-5
+    got = up.double().abs().sum().item()
+    assert abs(got - float(fx["up_abs_sum"])) / float(fx["up_abs_sum"]) < 1e-5
+
+
+@pytest.mark.parametrize("cfg,frames,B", [
+    (dict(layer_size=2, stack_size=2, input_channels=64, residual_channels=16, skip_channels=16), 2, 2),
+    (dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64), 4, 1),
+])
+def test_conditioned_forward_backward_vs_oracle(monkeypatch, cfg, frames, B):
+    import movenet_amd.wavenet as W
+    T = 1000 * frames
+    # Q8: the module constants fix the clip length; F frames <-> 1000 F samples
+    monkeypatch.setattr(W, "MAX_AUDIO_FRAMES", T)
+    monkeypatch.setattr(W, "MAX_VIDEO_FRAMES", frames)
+    sd = make_state_dict(**cfg, seed=17)
+    dims = O.Dims(**cfg)
+    Q = cfg["input_channels"]
+    x = one_hot(synthetic_indices(B, T, Q, 1234), Q)
+    rng = np.random.default_rng(4321)
+    video = torch.from_numpy(rng.random((B, frames, 64, 64, 1), dtype=np.float32))
+
+    # oracle (CPU autograd), trainer arithmetic
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ctx = O.upsample_video(params, video, expect_frames=T)
+    out_o = O.forward(params, dims, x, context=ctx)
+    target = x[:, :, dims.receptive_fields:].argmax(1)
+    loss_o = F.cross_entropy(out_o, target)
+    loss_o.backward()
+
+    m = _model(cfg, sd).train()
+    out = m(x.to(DEV), video.to(DEV))
+    assert out.shape == out_o.shape
+    assert np.abs(out.detach().cpu().numpy() - out_o.detach().numpy()).max() < 2e-6
+    with torch.no_grad():
+        logits = m(x.to(DEV), video.to(DEV), output_unnormalized=False, remove_last=False)
+        want = O.forward(sd, dims, x, context=ctx.detach(), output_unnormalized=False, remove_last=False)
+    assert rel_err(logits.cpu(), want) < 2e-5
+    loss = F.cross_entropy(out, target.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 2e-6
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    want_g = {k: p.grad for k, p in params.items() if p.grad is not None}
+    assert sorted(got) == sorted(want_g)  # video, context and decoder parameters all take part
+    for k in want_g:
+        assert rel_err(got[k].cpu(), want_g[k]) < 3e-4, k
+
+
+def test_conditioned_input_checks():
+    cfg = dict(layer_size=2, stack_size=2, input_channels=64, residual_channels=16, skip_channels=16)
+    m = _model(cfg, make_state_dict(**cfg, seed=1))
+    x = one_hot(synthetic_indices(1, 3000, 64, 1), 64).to(DEV)
+    video = torch.rand(1, 3, 64, 64, 1, device=DEV)
+    with pytest.raises(AssertionError):   # 3 frames upsample to 3000 != MAX_AUDIO_FRAMES (wavenet.py:155)
+        m(x, video)
+    with pytest.raises(ValueError):
+        m.upsample_video(torch.rand(1, 3, 32, 32, 1, device=DEV))
