@@ -132,11 +132,21 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *pa
  *               predicting time u is stored at [b][u - logits_t0] for u >= logits_t0.
  *  choices_out  optional (batch, n_total) int32: the class the model picks for
  *               time u, also where samples[] is teacher-forced (u >= logits_t0).
+ *  context_tm   optional local conditioning, see mvn_transpose_context below.
  */
 int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *state,
                  int32_t *samples, int batch, int sample_stride, int n_total, int n_given,
                  int t_begin, int t_end, float temperature, uint64_t seed,
-                 float *logits_out, int32_t *choices_out, int logits_t0, void *stream);
+                 float *logits_out, int32_t *choices_out, int logits_t0,
+                 const float *context_tm, void *stream);
+
+/* Local conditioning in generation (BUILD DEFINITION, the reference raises: SURVEY.md
+ * Q7): step t adds the context column of time t to every layer's filter/gate sums.
+ * context_tm is (batch, n_total, C) TIME-major (one coalesced 4C-byte read per step);
+ * mvn_transpose_context builds it from the (batch, C, ctx_ld) output of
+ * mvn_upsample_video.  GENERIC and PIPE variants only. */
+int mvn_transpose_context(const float *ctx, int ctx_ld, int batch, int channels, int t_len,
+                          float *context_tm, void *stream);
 
 /* ------------------------------------------------------------------------
  * Full-sequence forward (replaces movenet/wavenet.py:166-191: causal conv ->

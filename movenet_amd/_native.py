@@ -100,7 +100,9 @@ SIGNATURES = {
                                        C.c_void_p]),
     "mvn_generate": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mvn_transpose_context": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
     "mvn_padded_len": (C.c_int, [C.c_int]),
     "mvn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.POINTER(FwdBuffers), C.c_void_p, C.c_int, C.c_int,

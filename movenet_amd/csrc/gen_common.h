@@ -16,6 +16,11 @@ struct GenArgs {
   float *logits_out;
   int32_t *choices_out;
   int logits_t0;
+  // local conditioning (NULL = audio only): context (B, n_total, C) time-major and the
+  // packed context-conv section of the weight blob
+  const float *ctx_tm;
+  long long ctx_stride_b;
+  const float *wctx;
 };
 
 __device__ __forceinline__ int ring_offset(int l, int layer_size, int C) {
@@ -57,6 +62,7 @@ bool pipe_ok(const mvn_dims *d);
 int pipe_stages(const mvn_dims *d);
 size_t pipe_hand_floats(const mvn_dims *d, int batch);  // hand-off area appended to the state
 int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);
+int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s);
 int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s);
 
 }  // namespace mvn

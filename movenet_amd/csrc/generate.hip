@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void gen_generic_kernel(GenArgs a) {
   float *logits = a1 + Q;            // [Q]
   float *red = logits + Q;           // [16]
   int *ichoice = (int *)(red + 16);  // [4]
+  float *ctxv = red + 16 + 4;        // [C] context vector of this step
 
   const float *E0t = a.w, *E1t = a.w + (size_t)Q * C;
   const float *lw = a.w + 2 * (size_t)Q * C;
@@ -125,6 +126,9 @@ __global__ __launch_bounds__(256) void gen_generic_kernel(GenArgs a) {
       xcat[C + c] = v;
     }
     for (int k = tid; k < K; k += NT) skip[k] = 0.f;
+    if (a.ctx_tm)
+      for (int c = tid; c < C; c += NT)
+        ctxv[c] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)t * C + c];
     __syncthreads();
 
     for (int l = 0; l < L; ++l) {
@@ -136,7 +140,18 @@ __global__ __launch_bounds__(256) void gen_generic_kernel(GenArgs a) {
       matvec_parts(Wfg, xcat, 2 * C, 2 * C, part, Pfg, cfg);
       __syncthreads();
       for (int c = tid; c < C; c += NT) {
-        const float f = sum_parts(part, 2 * C, Pfg, c), g = sum_parts(part, 2 * C, Pfg, C + c);
+        float f = sum_parts(part, 2 * C, Pfg, c), g = sum_parts(part, 2 * C, Pfg, C + c);
+        if (a.ctx_tm) {
+          // 1x1 context convs (modules.py:58-63, :75-77; alignment = build definition)
+          const float *wc = a.wctx + (size_t)l * (2 * C * C + 2 * C), *bc = wc + 2 * C * C;
+          float cf = 0.f, cg = 0.f;
+          for (int k = 0; k < C; ++k) {
+            cf = fmaf(wc[(size_t)k * 2 * C + c], ctxv[k], cf);
+            cg = fmaf(wc[(size_t)k * 2 * C + C + c], ctxv[k], cg);
+          }
+          f += cf + bc[c];
+          g += cg + bc[C + c];
+        }
         zbuf[c] = gate(f, g);
         slot[c] = xcat[C + c];
       }
@@ -613,7 +628,30 @@ static size_t generic_lds_bytes(const mvn_dims *d) {
   if (2 * C > partsz) partsz = 2 * C;
   if (C + K > partsz) partsz = C + K;
   if (Q > partsz) partsz = Q;
-  return sizeof(float) * ((size_t)2 * C + (size_t)L * C + partsz + C + 2 * K + 2 * Q + 16 + 4);
+  return sizeof(float) * ((size_t)2 * C + (size_t)L * C + partsz + C + 2 * K + 2 * Q + 16 + 4 + C);
+}
+
+// packed blob without the trailing context-conv section
+static size_t gen_base_floats(const mvn_dims *dims, int variant) {
+  const size_t C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
+  const size_t L = n_layers(dims);
+  if (variant == MVN_GEN_STREAM || variant == MVN_GEN_PIPE)
+    return s64::EMB_FLOATS + 4 * (L * s64::LAYER_F4 + s64::HEAD_F4);
+  return 2 * Q * C + L * (4 * C * C + C * (C + K) + (C + K)) + K * Q + Q + Q * Q + Q;
+}
+
+// generic context section: per layer Wt[k (C)][o (2C): f | g] then bias[2C]
+__global__ void pack_ctx_generic_kernel(const float *wcf, const float *bcf, const float *wcg,
+                                        const float *bcg, float *__restrict__ dst, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nw = 2 * C * C;
+  if (i < nw) {
+    const int k = i / (2 * C), o = i - k * 2 * C;
+    dst[i] = o < C ? wcf[(size_t)o * C + k] : wcg[(size_t)(o - C) * C + k];
+  } else if (i < nw + 2 * C) {
+    const int o = i - nw;
+    dst[i] = o < C ? bcf[o] : bcg[o - C];
+  }
 }
 
 static bool stream_ok(const mvn_dims *d) {
@@ -623,7 +661,39 @@ static bool stream_ok(const mvn_dims *d) {
 
 }  // namespace mvn
 
+namespace mvn {
+// (B, C, ld) -> (B, T, C): 32x32 tiles through LDS, both sides coalesced
+__global__ void transpose_ctx_kernel(const float *__restrict__ src, int ld, float *__restrict__ dst,
+                                     int C, int T) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, t = t0 + tx;
+    tile[r][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * ld + t] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int t = t0 + r, c = c0 + tx;
+    if (t < T && c < C) dst[((size_t)b * T + t) * C + c] = tile[tx][r];
+  }
+}
+}  // namespace mvn
+
 extern "C" {
+
+int mvn_transpose_context(const float *ctx, int ctx_ld, int batch, int channels, int t_len,
+                          float *context_tm, void *stream) {
+  if (!ctx || !context_tm || batch < 0 || channels < 1 || t_len < 1 || ctx_ld < t_len) {
+    mvn::set_error("mvn_transpose_context: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0) return MVN_OK;
+  dim3 grid((t_len + 31) / 32, (channels + 31) / 32, batch);
+  hipLaunchKernelGGL(mvn::transpose_ctx_kernel, grid, dim3(256), 0, (hipStream_t)stream, ctx, ctx_ld,
+                     context_tm, channels, t_len);
+  return mvn::check_hip(hipGetLastError(), "mvn_transpose_context");
+}
 
 static int device_cus() {
   int dev = 0, cus = 0;
@@ -673,9 +743,7 @@ size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant) {
   if (variant < 0) return 0;
   const size_t C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const size_t L = mvn::n_layers(dims);
-  if (variant == MVN_GEN_STREAM || variant == MVN_GEN_PIPE)
-    return mvn::s64::EMB_FLOATS + 4 * (L * mvn::s64::LAYER_F4 + mvn::s64::HEAD_F4);
-  return 2 * Q * C + L * (4 * C * C + C * (C + K) + (C + K)) + K * Q + Q + Q * Q + Q;
+  return mvn::gen_base_floats(dims, variant) + L * (2 * C * C + 2 * C);  // + context-conv section
 }
 
 size_t mvn_gen_state_floats(const mvn_dims *dims, int batch) {
@@ -701,7 +769,20 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
     return MVN_ERR_BAD_ARG;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  if (variant == MVN_GEN_PIPE) return mvn::pipe_pack(dims, p, packed, stream);
+  const bool has_ctx = p->ctx_filter_w && p->ctx_filter_b && p->ctx_gate_w && p->ctx_gate_b;
+  float *ctx_section = packed + mvn::gen_base_floats(dims, variant);
+  if (variant == MVN_GEN_PIPE) {
+    int rc = mvn::pipe_pack(dims, p, packed, stream);
+    if (rc || !has_ctx) return rc;
+    return mvn::pipe_pack_ctx(dims, p, ctx_section, stream);
+  }
+  if (has_ctx && variant == MVN_GEN_GENERIC) {
+    const int Cc = dims->residual_channels, n = 2 * Cc * Cc + 2 * Cc;
+    for (int l = 0; l < mvn::n_layers(dims); ++l)
+      hipLaunchKernelGGL(mvn::pack_ctx_generic_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                         p->ctx_filter_w[l], p->ctx_filter_b[l], p->ctx_gate_w[l], p->ctx_gate_b[l],
+                         ctx_section + (size_t)l * n, Cc);
+  }
   const int C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const int L = mvn::n_layers(dims);
   {
@@ -735,7 +816,7 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
 int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *state,
                  int32_t *samples, int batch, int sample_stride, int n_total, int n_given,
                  int t_begin, int t_end, float temperature, uint64_t seed, float *logits_out,
-                 int32_t *choices_out, int logits_t0, void *stream) {
+                 int32_t *choices_out, int logits_t0, const float *context_tm, void *stream) {
   if (variant == MVN_GEN_AUTO) {
     mvn::set_error("mvn_generate: resolve the variant with mvn_gen_variant first (the packed "
                    "weight layout depends on it)");
@@ -772,6 +853,13 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
   a.logits_out = logits_out;
   a.choices_out = choices_out;
   a.logits_t0 = logits_t0;
+  a.ctx_tm = context_tm;
+  a.ctx_stride_b = (long long)n_total * dims->residual_channels;
+  a.wctx = packed + mvn::gen_base_floats(dims, variant);
+  if (context_tm && variant == MVN_GEN_STREAM) {
+    mvn::set_error("local conditioning is built for the GENERIC and PIPE generator variants only");
+    return MVN_ERR_UNSUPPORTED;
+  }
   if (variant == MVN_GEN_PIPE) {
     float *hand = state + (size_t)batch * a.state_per_seq;
     return mvn::pipe_launch(a, dims, batch, hand, (hipStream_t)stream);

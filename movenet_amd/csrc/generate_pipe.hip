@@ -35,6 +35,7 @@ constexpr int LAYER_F = 3 * MAT_F + 128;     // WC | WP | WR | brs
 constexpr int EMB_F = 2 * Q * C;
 constexpr int W1_F = Q * C, W2_F = Q * Q;
 constexpr int HEAD_F = W1_F + Q + W2_F + Q;
+constexpr int CTX_LAYER_F = MAT_F + 128;     // context section per layer: Wcf|Wcg rows + biases
 constexpr int GRAN = 128;                    // granules per inbox
 constexpr int LDS_FLOATS = 33408;            // max(layer stage, head stage) + 16 flag words
 constexpr unsigned SPIN_LIMIT = 1u << 23;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     float *zb = cur + 64;              // [64] gated activation
     float *pastb = zb + 64;            // [LPS][64] popped queue entries
     float *skin = pastb + LPS * 64;    // [64] running skip sum as received
+    float *ctxb = skin + 64;           // [64] context vector of the step being prepared
     float *ring = a.state + (size_t)b * a.state_per_seq;
 
     v2f wa[LPS][8], wb[LPS][8];        // FG: f_c | g_c current-tap rows; RS: res_c | skip_c rows
@@ -313,6 +315,8 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
             pastb[j * 64 + c] = pv;
           }
       }
+      if (a.ctx_tm && fg_group && t < 64)
+        ctxb[t] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + t];
       __syncthreads();
       if (fg_group) {
 #pragma unroll
@@ -324,6 +328,16 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
             const f4 x[4] = {x4[0], x4[1], x4[2], x4[3]};
             pf[j] = quad_sum(dot16(qa, x));
             pg[j] = quad_sum(dot16(qb, x));
+            if (a.ctx_tm) {
+              // 1x1 context convs (modules.py:58-63, :75-77): their weights are streamed
+              // from L2 here, off the critical path (32 KB per layer per step)
+              const float *wc = a.wctx + (size_t)(l0 + j) * CTX_LAYER_F;
+              load2x16(qa, qb, (const f4 *)wc, 256, t);
+              const f4 *c4 = (const f4 *)(ctxb + 16 * kq);
+              const f4 cx[4] = {c4[0], c4[1], c4[2], c4[3]};
+              pf[j] += quad_sum(dot16(qa, cx)) + wc[MAT_F + c];
+              pg[j] += quad_sum(dot16(qb, cx)) + wc[MAT_F + 64 + c];
+            }
           }
       }
     };
@@ -623,6 +637,31 @@ __global__ void pack_embed_p64_kernel(const float *__restrict__ causal_w, float 
   if (i >= EMB_F) return;
   const int tap = i / (Q * C), r = i - tap * Q * C, qq = r / C, c = r - qq * C;
   dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
+}
+
+__global__ void pack_ctx_p64_kernel(const float *wcf, const float *bcf, const float *wcg,
+                                    const float *bcg, float *__restrict__ dst) {
+  using namespace p64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CTX_LAYER_F) return;
+  if (i >= MAT_F) {
+    const int o = i - MAT_F;
+    dst[i] = o < C ? bcf[o] : bcg[o - C];
+    return;
+  }
+  // same thread mapping as the current-tap matrix: thread t = 4*c + kq owns rows (c, 64+c)
+  const int e = i & 3, v = i >> 2, t = v & 255, i8 = v >> 8;
+  const int c = t >> 2, k = 16 * (t & 3) + 4 * (i8 & 3) + e;
+  dst[i] = (i8 >> 2) ? wcg[(size_t)c * C + k] : wcf[(size_t)c * C + k];
+}
+
+int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s) {
+  using namespace p64;
+  for (int l = 0; l < n_layers(d); ++l)
+    hipLaunchKernelGGL(pack_ctx_p64_kernel, dim3((CTX_LAYER_F + 255) / 256), dim3(256), 0, s,
+                       p->ctx_filter_w[l], p->ctx_filter_b[l], p->ctx_gate_w[l], p->ctx_gate_b[l],
+                       ctx_section + (size_t)l * CTX_LAYER_F);
+  return check_hip(hipGetLastError(), "pipe_pack_ctx");
 }
 
 bool pipe_ok(const mvn_dims *d) {

@@ -79,7 +79,8 @@ class RingGenerator:
     def __init__(self, layer_size: int, stack_size: int, input_channels: int,
                  residual_channels: int, skip_channels: int, state_dict: Dict[str, torch.Tensor],
                  batch: int, n_total: int, device, variant: int = N.GEN_AUTO,
-                 temperature: float = 0.0, seed: int = 0):
+                 temperature: float = 0.0, seed: int = 0,
+                 context: Optional[torch.Tensor] = None):
         self.lib = N.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -93,6 +94,24 @@ class RingGenerator:
         with torch.cuda.device(self.device):
             self.variant = N.check(self.lib.mvn_gen_variant(self.dims, variant, self.batch),
                                    "mvn_gen_variant")
+            if context is not None and self.variant == N.GEN_STREAM:
+                self.variant = N.GEN_GENERIC  # conditioning: GENERIC and PIPE variants only
+        self.context = None      # (B, C, >= n_total) upsampled video as given
+        self.context_tm = None   # (B, n_total, C) time-major copy the kernels read
+        if context is not None:
+            _require_gpu(context, "context")
+            if context.shape[0] != batch or context.shape[1] != residual_channels or \
+                    context.shape[2] < n_total:
+                raise ValueError(f"context must be (batch, {residual_channels}, >= n_total), "
+                                 f"got {tuple(context.shape)}")
+            self.context = context.detach().to(torch.float32).contiguous()
+            with torch.cuda.device(self.device):
+                self.context_tm = torch.empty(self.batch, self.n_total, residual_channels,
+                                              dtype=torch.float32, device=self.device)
+                N.check(self.lib.mvn_transpose_context(
+                    self.context.data_ptr(), self.context.stride(1), self.batch, residual_channels,
+                    self.n_total, self.context_tm.data_ptr(), _stream_ptr(self.device)),
+                    "mvn_transpose_context")
         self.temperature, self.seed = float(temperature), int(seed) & (2 ** 64 - 1)
         with torch.cuda.device(self.device):
             nw = self.lib.mvn_gen_weights_floats(self.dims, self.variant)
@@ -140,7 +159,8 @@ class RingGenerator:
                 t_begin, t_end, self.temperature, self.seed,
                 None if logits_out is None else logits_out.data_ptr(),
                 None if choices_out is None else choices_out.data_ptr(),
-                logits_t0, _stream_ptr(self.device)), "mvn_generate")
+                logits_t0, None if self.context_tm is None else self.context_tm.data_ptr(),
+                _stream_ptr(self.device)), "mvn_generate")
 
     def prime(self, prompt_idx: torch.Tensor) -> None:
         """Load a (B, P) prompt (P >= 1 class indices per sequence) and run the
@@ -159,7 +179,8 @@ class RingGenerator:
             # each layer's most recent d_l inputs into its queue
             from .ops import run_forward
             idx = self.samples[:, :P].contiguous()
-            _, buf = run_forward(self.dims, self._sd, idx, False, False, save=True)
+            ctx = None if self.context is None else self.context[:, :, :P]
+            _, buf = run_forward(self.dims, self._sd, idx, False, False, save=True, ctx=ctx)
             with torch.cuda.device(self.device):
                 N.check(self.lib.mvn_gen_prime_from_forward(
                     self.dims, buf.struct, self.batch, P, self.state.data_ptr(),

@@ -173,9 +173,9 @@ class WaveNet(nn.Module):
         """wavenet.py:193-239: copy the first RF prompt samples, then generate
         autoregressively up to n_samples (default: the prompt's own length)."""
         self.eval()  # the reference leaves the module in eval mode (SURVEY Q10)
-        if video is not None:
-            raise NotImplementedError(
-                "conditioned generation raises in the reference itself (SURVEY.md Q7)")
+        # BUILD DEFINITION for video != None (the reference fails its size assert there,
+        # SURVEY.md Q7): the context column of time t conditions the step that consumes x_t
+        context = None if video is None else self.upsample_video(video)
         rf = self.receptive_fields
         n_total = int(audio.shape[2]) if n_samples is None else int(n_samples)
         idx = self._indices_of(audio)
@@ -187,10 +187,17 @@ class WaveNet(nn.Module):
             out[:, :, :n] = audio[:, :, :n]
             return out
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        state = self._decoder_state()
+        if context is None:
+            state = {k: v for k, v in state.items() if ".context_conv_" not in k}
+        elif context.shape[2] < n_total:
+            raise ValueError(f"the upsampled video covers {context.shape[2]} samples, "
+                             f"n_samples={n_total} asked for")
         gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
-                            self.residual_channels, self.skip_channels, self._decoder_state(),
+                            self.residual_channels, self.skip_channels, state,
                             batch=idx.shape[0], n_total=n_total, device=audio.device,
-                            variant=self._gen_variant, temperature=float(temperature), seed=seed)
+                            variant=self._gen_variant, temperature=float(temperature), seed=seed,
+                            context=context)
         gen.prime(idx[:, :rf])
         gen.advance(n_total - rf)
         return self._one_hot_of(gen.samples, audio.dtype)

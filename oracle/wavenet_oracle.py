@@ -163,7 +163,7 @@ def pre_sampling_probs(probs: torch.Tensor, temperature: float) -> torch.Tensor:
 def generate_windowed(sd: Dict[str, torch.Tensor], dims: Dims, audio: torch.Tensor,
                       n_samples: Optional[int] = None, temperature: float = 1.0,
                       generator: Optional[torch.Generator] = None,
-                      return_margins: bool = False):
+                      return_margins: bool = False, context: Optional[torch.Tensor] = None):
     """movenet/wavenet.py:193-239 -- the reference's NAIVE algorithm: one full
     forward over the last RF samples per generated sample.  This is what the
     CPU baseline times."""
@@ -173,7 +173,11 @@ def generate_windowed(sd: Dict[str, torch.Tensor], dims: Dims, audio: torch.Tens
     gen[:, :, :rf] = audio[:, :, :rf]
     margins = []
     for i in range(rf, shape[-1]):
-        out = forward(sd, dims, gen[:, :, i - rf:i], output_unnormalized=True, remove_last=False)
+        # BUILD DEFINITION with context: the window sees the context columns of its own
+        # times (the reference passes the whole context and fails its assert)
+        ctx = None if context is None else context[:, :, i - rf:i]
+        out = forward(sd, dims, gen[:, :, i - rf:i], output_unnormalized=True, remove_last=False,
+                      context=ctx)
         assert out.shape[2] == 1
         p2 = pre_sampling_probs(out, temperature)
         if temperature > 0:
@@ -209,6 +213,10 @@ class RingState:
             wg = g(_layer_key(l, "conv_gate.conv.weight"))
             self.layers.append(dict(
                 d=d, wf0=wf[:, :, 0], wf1=wf[:, :, 1], wg0=wg[:, :, 0], wg1=wg[:, :, 1],
+                wcf=g(_layer_key(l, "context_conv_filter.weight"))[:, :, 0],
+                bcf=g(_layer_key(l, "context_conv_filter.bias")),
+                wcg=g(_layer_key(l, "context_conv_gate.weight"))[:, :, 0],
+                bcg=g(_layer_key(l, "context_conv_gate.bias")),
                 wr=g(_layer_key(l, "conv_residual.weight"))[:, :, 0],
                 br=g(_layer_key(l, "conv_residual.bias")),
                 ws=g(_layer_key(l, "conv_skip.weight"))[:, :, 0],
@@ -222,10 +230,11 @@ class RingState:
         self.t = 0
         self.prev = None  # index at t-1 (None => x[-1] = 0, the conv's zero pad)
 
-    def step(self, idx: np.ndarray) -> np.ndarray:
+    def step(self, idx: np.ndarray, ctx_t: Optional[np.ndarray] = None) -> np.ndarray:
         """Consume the sample at time t (class indices, shape (B,)), return the
         raw logits (B,Q) predicting time t+1.  Logits are only meaningful once
-        t >= RF-1 (before that the valid-convolution stack has no output)."""
+        t >= RF-1 (before that the valid-convolution stack has no output).
+        ctx_t: optional (B,C) context column of time t (build-defined alignment)."""
         h = self.E1[:, idx].T.copy()
         if self.prev is not None:
             h += self.E0[:, self.prev].T
@@ -236,6 +245,9 @@ class RingState:
             L["ring"][slot] = h
             f = past @ L["wf0"].T + h @ L["wf1"].T
             g = past @ L["wg0"].T + h @ L["wg1"].T
+            if ctx_t is not None:
+                f = f + (ctx_t @ L["wcf"].T + L["bcf"])
+                g = g + (ctx_t @ L["wcg"].T + L["bcg"])
             z = np.tanh(f) * (1.0 / (1.0 + np.exp(-g)))
             z = z.astype(np.float32)
             skip += z @ L["ws"].T + L["bs"]
@@ -250,7 +262,8 @@ class RingState:
 
 
 def generate_ring(sd: Dict[str, torch.Tensor], dims: Dims, prompt_idx: np.ndarray,
-                  n_samples: int, forced_idx: Optional[np.ndarray] = None):
+                  n_samples: int, forced_idx: Optional[np.ndarray] = None,
+                  context: Optional[np.ndarray] = None):
     """Greedy (temperature<=0) ring-buffer generation.  prompt_idx (B, >=RF).
     Returns (choices (B,n_samples) int64, logits (B, n_samples-RF, Q)); the
     first RF columns of ``choices`` are the prompt.  With ``forced_idx``
@@ -268,7 +281,7 @@ def generate_ring(sd: Dict[str, torch.Tensor], dims: Dims, prompt_idx: np.ndarra
             logits[:, t - rf] = lg
             choices[:, t] = _double_softmax_argmax(lg)
         fed = choices[:, t] if (forced_idx is None or t < rf) else forced_idx[:, t]
-        lg = st.step(fed)
+        lg = st.step(fed, None if context is None else context[:, :, t])
     return choices, logits
 
 

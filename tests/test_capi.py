@@ -53,9 +53,11 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_variant(d1, N.GEN_STREAM, 2) == N.MVN_ERR_UNSUPPORTED
     assert lib.mvn_gen_variant(d1, N.GEN_PIPE, 2) == N.MVN_ERR_UNSUPPORTED
     # audio-path parameters of the 30-layer model
-    assert lib.mvn_gen_weights_floats(d2, N.GEN_GENERIC) == 856320
-    assert lib.mvn_gen_weights_floats(d2, N.GEN_STREAM) == 856320
-    assert lib.mvn_gen_weights_floats(d2, N.GEN_PIPE) == 856320
+    # + the context-conv section: 30 layers x (128x64 weights + 128 biases)
+    ctx = 30 * (128 * 64 + 128)
+    assert lib.mvn_gen_weights_floats(d2, N.GEN_GENERIC) == 856320 + ctx
+    assert lib.mvn_gen_weights_floats(d2, N.GEN_STREAM) == 856320 + ctx
+    assert lib.mvn_gen_weights_floats(d2, N.GEN_PIPE) == 856320 + ctx
     # dilation queues: D*C floats per sequence (786 KB fp32) + the PIPE
     # variant's hand-off area (9 stages x 128 eight-byte granules per sequence + flags)
     assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 9 * 256 + 64
@@ -66,7 +68,7 @@ def test_generate_sizes_and_variants():
 def test_bad_arguments_are_refused_before_any_launch():
     lib = N.lib()
     d2 = N.make_dims(10, 3, 256, 64, 64)
-    rc = lib.mvn_generate(d2, N.GEN_STREAM, None, None, None, 1, 10, 10, 1, 0, 5, 0.0, 0, None, None, 0, None)
+    rc = lib.mvn_generate(d2, N.GEN_STREAM, None, None, None, 1, 10, 10, 1, 0, 5, 0.0, 0, None, None, 0, None, None)
     assert rc == N.MVN_ERR_BAD_ARG
     with pytest.raises(ValueError):
         N.check(rc, "mvn_generate")
