@@ -58,13 +58,19 @@ class SyntheticLoader:
 
     def __init__(self, spec: str, input_channels: int, batch_size: int, train: bool = True,
                  rank: int = 0, world_size: int = 1, shuffle: bool = False,
-                 batch_subsample_frac: Optional[float] = None, **_ignored):
+                 batch_subsample_frac: Optional[float] = None, use_video: bool = False,
+                 **_ignored):
         cfg = parse_synthetic(spec)
         self.n_clips, self.frames = cfg["clips"], cfg["frames"]
         self.seed = cfg["seed"] + (0 if train else 10007)
         self.Q, self.batch_size = input_channels, batch_size
         self.rank, self.world = rank, max(world_size, 1)
         self.shuffle, self.frac = shuffle, batch_subsample_frac
+        self.use_video = use_video
+        if use_video and (self.frames % 1000 or batch_subsample_frac is not None):
+            raise ValueError("video batches need frames % 1000 == 0 and no batch_subsample_frac "
+                             "(the reference crops audio and video independently, dataset.py:232-242, "
+                             "which its own size assert then rejects)")
         self.epoch = 0
 
     def set_epoch(self, epoch: int) -> None:
@@ -97,7 +103,14 @@ class SyntheticLoader:
                 n = math.ceil(audio.shape[-1] * self.frac)
                 start = crop_rng.randint(0, audio.shape[-1] - n)
                 audio = audio[..., start:start + n]
-            yield Batch(audio, None, ["synthetic"] * len(ids),
+            video = None
+            if self.use_video:
+                # U[0,1) frames, one 64x64 gray frame per 1000 samples
+                # (movenet/wavenet.py:27-31: 160 frames <-> 160000 samples)
+                vr = np.random.default_rng(self.seed * 7919 + 4321 + ids[0])
+                video = torch.from_numpy(
+                    vr.random((len(ids), self.frames // 1000, 64, 64, 1), dtype=np.float32))
+            yield Batch(audio, video, ["synthetic"] * len(ids),
                         [f"synthetic://{i}" for i in ids],
                         [dict(video_fps=0.0, audio_fps=float(self.frames) / 10.0)] * len(ids))
 
@@ -107,13 +120,9 @@ def get_dataloader(filepath, input_channels: int, batch_size: int = 64, train: b
                    normalize_audio: bool = True, batch_subsample_frac: Optional[float] = None,
                    **kwargs) -> SyntheticLoader:
     """Signature of movenet/dataset.py:59-98."""
-    if use_video:
-        raise NotImplementedError(
-            "video batches are not built: the reference's conditioned forward raises "
-            "(SURVEY.md Q6); pass --use_video 0")
     return SyntheticLoader(str(filepath), input_channels, batch_size, train=train, rank=rank,
                            world_size=world_size, shuffle=kwargs.get("shuffle", False),
-                           batch_subsample_frac=batch_subsample_frac)
+                           batch_subsample_frac=batch_subsample_frac, use_video=use_video)
 
 
 # -- mu-law companding: the formula the project states (RESEARCH.md:156-163).

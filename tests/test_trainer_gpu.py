@@ -75,3 +75,25 @@ def test_gradient_accumulation_and_clipping_run(tmp_path):
                  accumulate_grad_batches=2)
     tr.fit(m)
     assert len(tr.history) == 2 and all(np.isfinite(h["train_loss"]) for h in tr.history)
+
+
+def test_video_conditioned_training_runs(tmp_path, monkeypatch):
+    """use_video=1 end to end (encoder, upsampler, context convs, their gradients) on a
+    2-frame / 2000-sample clip; every parameter of the model now receives a gradient
+    except the last layer's residual conv."""
+    import movenet_amd.wavenet as W
+    from movenet_amd.pytorch_lightning_trainer import Dance2Music, Trainer
+    monkeypatch.setattr(W, "MAX_AUDIO_FRAMES", 2000)
+    monkeypatch.setattr(W, "MAX_VIDEO_FRAMES", 2)
+    cfg = TrainingConfig(model_config=ModelConfig(2, 2, 64, 16, 16), batch_size=2, n_epochs=1,
+                         use_video=True, scheduler=None, model_output_path=tmp_path)
+    m = Dance2Music("synthetic://clips=4,frames=2000,seed=2", cfg)
+    before = {k: v.clone() for k, v in m.model.state_dict().items()}
+    tr = Trainer(max_epochs=1, default_root_dir=None)
+    tr.fit(m)
+    assert len(tr.history) == 2 and all(np.isfinite(h["train_loss"]) for h in tr.history)
+    after = m.model.state_dict()
+    changed = {k for k in before if not torch.equal(before[k], after[k].cpu())}
+    assert "video_conv.weight" in changed and "video_transpose.2.bias" in changed
+    assert "residual_conv_stack.conv_layers.0.context_conv_gate.weight" in changed
+    assert "residual_conv_stack.conv_layers.3.conv_residual.weight" not in changed

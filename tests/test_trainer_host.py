@@ -64,8 +64,10 @@ def test_synthetic_batches_and_sharding():
     crop = next(iter(get_dataloader("synthetic://clips=2,frames=100", 16, 2, use_video=False,
                                     batch_subsample_frac=0.25)))
     assert crop.audio.shape == (2, 16, 25)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         get_dataloader("synthetic://clips=2,frames=100", 16, 2, use_video=True)
+    vb = next(iter(get_dataloader("synthetic://clips=2,frames=2000", 16, 2, use_video=True)))
+    assert vb.video.shape == (2, 2, 64, 64, 1) and vb.audio.shape == (2, 16, 2000)
     with pytest.raises(ValueError):
         get_dataloader("/data/kinetics", 16, 2, use_video=False)
 
