@@ -188,12 +188,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and a
+    # gloo process group, to exercise the N>1 control flow without a second GPU
+    if os.environ.get("MOVENET_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MOVENET_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from movenet_amd.generation import RingGenerator
     from movenet_amd.utils.weights import make_state_dict, synthetic_indices

@@ -176,6 +176,10 @@ typedef struct mvn_fwd_buffers {
                        DEFINITION of the alignment: the reference raises at
                        modules.py:75-77                          */
   int32_t ctx_ld;
+  const float *dense_audio; /* optional (B, Q, dense_ld) fp32 input that is NOT one-hot: the
+                               causal conv then runs as a dense product and `index` is
+                               ignored (may be NULL); NULL = use `index`                */
+  int32_t dense_ld;
 } mvn_fwd_buffers;
 
 /* out: (B, Q, S_out) contiguous, S_out = S - (remove_last ? 1 : 0); softmax over

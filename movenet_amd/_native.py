@@ -60,7 +60,8 @@ _FP = C.POINTER(C.c_void_p)
 
 class FwdBuffers(C.Structure):
     _fields_ = [("acts", C.c_void_p), ("th", C.c_void_p), ("sg", C.c_void_p), ("z", C.c_void_p),
-                ("skip", C.c_void_p), ("a1", C.c_void_p), ("ctx", C.c_void_p), ("ctx_ld", C.c_int32)]
+                ("skip", C.c_void_p), ("a1", C.c_void_p), ("ctx", C.c_void_p), ("ctx_ld", C.c_int32),
+                ("dense_audio", C.c_void_p), ("dense_ld", C.c_int32)]
 
 
 class ParamGrads(C.Structure):

@@ -169,6 +169,54 @@ struct DenseOp {
   }
 };
 
+// A0 (dense input): the causal conv on an arbitrary (B,Q,T) float input
+// (modules.py:19-30: k=2, padding 1, last column dropped): K = 2Q, column k < Q is
+// tap 0 on x[t-1] (zero at t = 0), k >= Q is tap 1 on x[t].  One-hot inputs take the
+// gather path (embed_kernel) instead.
+struct CausalOp {
+  int K, t_begin, t_end, C, Q;
+  const float *cw;  // (C, Q, 2)
+  Act audio, x0;
+  __device__ __forceinline__ float w(int m, int k) const {
+    if (m >= C || k >= 2 * Q) return 0.f;
+    const int tap = k >= Q, q = k - tap * Q;
+    return cw[((size_t)m * Q + q) * 2 + tap];
+  }
+  __device__ __forceinline__ float x(int b, int k, int t) const {
+    if (k >= 2 * Q || t >= t_end) return 0.f;
+    if (k < Q) return t > 0 ? *audio.at(b, k, t - 1) : 0.f;
+    return *audio.at(b, k - Q, t);
+  }
+  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
+                                           const f32x16 &a1) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m0 = mb * 64 + acc_row(r, lane), m1 = m0 + 32;
+      if (m0 < C) *x0.at(b, m0, t) = a0[r];
+      if (m1 < C) *x0.at(b, m1, t) = a1[r];
+    }
+  }
+};
+struct WgCausalOp {
+  int t_begin, t_end, C, Q;
+  Act dx0, audio;
+  float *dcw;
+  __device__ __forceinline__ float a(int b, int m, int t) const {
+    return m < C ? *dx0.at(b, m, t) : 0.f;
+  }
+  __device__ __forceinline__ float x(int b, int n, int t) const {
+    if (n >= 2 * Q) return 0.f;
+    if (n < Q) return t > 0 ? *audio.at(b, n, t - 1) : 0.f;
+    return *audio.at(b, n - Q, t);
+  }
+  __device__ __forceinline__ float *dw(int m, int n) const {
+    if (m >= C || n >= 2 * Q) return nullptr;
+    const int tap = n >= Q, q = n - tap * Q;
+    return dcw + ((size_t)m * Q + q) * 2 + tap;
+  }
+  __device__ __forceinline__ float *db(int m) const { return nullptr; }
+};
+
 // ---- backward data-gradient ops ------------------------------------------
 // B3: dz = Wr^T dxo + Ws^T dskip ; df = dz*sg*(1-th^2) ; dg = dz*th*sg*(1-sg)
 struct DzOp {
@@ -484,9 +532,10 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
   Geometry g;
   int rc = make_geometry(dims, batch, t_len, g);
   if (rc) return rc;
-  if (!p || !index || !buf || !buf->acts || !buf->z || !buf->skip || !buf->a1 ||
-      (save && (!buf->th || !buf->sg)) || index_stride < t_len) {
-    set_error("mvn_forward: NULL buffer or bad index stride");
+  if (!p || !buf || !buf->acts || !buf->z || !buf->skip || !buf->a1 ||
+      (save && (!buf->th || !buf->sg)) ||
+      (buf->dense_audio ? buf->dense_ld < t_len : (!index || index_stride < t_len))) {
+    set_error("mvn_forward: NULL buffer or bad index / dense-audio stride");
     return MVN_ERR_BAD_ARG;
   }
   const int S_out = g.S - (remove_last ? 1 : 0);
@@ -500,8 +549,16 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
   const int t_skip0 = g.rf - 1;
 
   Act x0 = act_view(buf->acts, batch, C, g.Tp);
-  hipLaunchKernelGGL(embed_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, p->causal_w,
-                     index, index_stride, x0, C, Q, T);
+  if (buf->dense_audio) {
+    CausalOp c0;
+    c0.K = 2 * Q; c0.t_begin = 0; c0.t_end = T; c0.C = C; c0.Q = Q; c0.cw = p->causal_w;
+    c0.audio = act_view(const_cast<float *>(buf->dense_audio), batch, Q, buf->dense_ld);
+    c0.x0 = x0;
+    launch_gemm(c0, C, batch, s);
+  } else {
+    hipLaunchKernelGGL(embed_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, p->causal_w,
+                       index, index_stride, x0, C, Q, T);
+  }
   Act zv = act_view(buf->z, batch, C, g.Tp);
   Act skipv = act_view(buf->skip, batch, Kc, g.Sp);
   const bool has_ctx = buf->ctx != nullptr;
@@ -563,7 +620,11 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   Geometry g;
   int rc = make_geometry(dims, batch, t_len, g);
   if (rc) return rc;
-  if (!p || !gr || !index || !fwd || !bwd || !fwd->acts || !fwd->th || !fwd->sg || !fwd->skip ||
+  if (fwd && !fwd->dense_audio && !index) {
+    set_error("mvn_backward: index is NULL");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (!p || !gr || !fwd || !bwd || !fwd->acts || !fwd->th || !fwd->sg || !fwd->skip ||
       !fwd->a1 || !bwd->dx_a || !bwd->dx_b || !bwd->dfg || !bwd->dskip || !bwd->da1 ||
       !bwd->dlogit || !dout || (normalize && !out)) {
     set_error("mvn_backward: NULL buffer");
@@ -679,8 +740,16 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     dxo_p = cur;
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
-  hipLaunchKernelGGL(embed_grad_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s,
-                     gr->causal_w, index, index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T);
+  if (fwd->dense_audio) {
+    WgCausalOp wc;
+    wc.t_begin = 0; wc.t_end = T; wc.C = C; wc.Q = Q; wc.dx0 = act_view(dxo_p, batch, C, g.Tp);
+    wc.audio = act_view(const_cast<float *>(fwd->dense_audio), batch, Q, fwd->dense_ld);
+    wc.dcw = gr->causal_w;
+    launch_wgrad(wc, C, 2 * Q, batch, nullptr, s);
+  } else {
+    hipLaunchKernelGGL(embed_grad_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s,
+                       gr->causal_w, index, index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T);
+  }
   return check_hip(hipGetLastError(), "mvn_backward");
 }
 

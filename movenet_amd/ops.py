@@ -43,7 +43,8 @@ def decoder_param_names(n_layers: int, with_context: bool = False) -> List[str]:
 class ForwardBuffers:
     """Device buffers of one forward pass (sizes: include/movenet_hip.h)."""
 
-    def __init__(self, dims: N.Dims, batch: int, t_len: int, save: bool, device, ctx=None):
+    def __init__(self, dims: N.Dims, batch: int, t_len: int, save: bool, device, ctx=None,
+                 dense=None):
         lib = N.lib()
         L = dims.layer_size * dims.stack_size
         C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
@@ -61,14 +62,23 @@ class ForwardBuffers:
             self.acts.data_ptr(), self.th.data_ptr() if save else None,
             self.sg.data_ptr() if save else None, self.z.data_ptr(), self.skip.data_ptr(),
             self.a1.data_ptr(), None if ctx is None else ctx.data_ptr(),
-            0 if ctx is None else ctx.stride(1))
+            0 if ctx is None else ctx.stride(1),
+            None if dense is None else dense.data_ptr(), 0 if dense is None else dense.stride(1))
+        self.dense = dense
 
 
 def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, normalize: bool,
                 remove_last: bool, save: bool, ctx=None) -> Tuple[torch.Tensor, ForwardBuffers]:
+    """idx: (B,T) int32 class indices, or a (B,Q,T) fp32 tensor for inputs that are
+    not one-hot (dense causal conv)."""
     lib = N.lib()
-    _require_gpu(idx, "audio indices")
-    B, T = idx.shape
+    _require_gpu(idx, "audio")
+    dense = None
+    if idx.dim() == 3:
+        dense = idx.detach().to(torch.float32).contiguous()
+        B, _, T = dense.shape
+    else:
+        B, T = idx.shape
     L = dims.layer_size * dims.stack_size
     dev = idx.device
     if ctx is not None:
@@ -78,11 +88,12 @@ def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, no
             f"{tuple(ctx.shape)}, {(B, dims.residual_channels, T)}")
         ctx = ctx.detach().to(torch.float32).contiguous()
     with torch.cuda.device(dev):
-        buf = ForwardBuffers(dims, B, T, save, dev, ctx)
+        buf = ForwardBuffers(dims, B, T, save, dev, ctx, dense)
         s_out = buf.S - (1 if remove_last else 0)
         out = torch.empty((B, dims.input_channels, max(s_out, 0)), dtype=torch.float32, device=dev)
         params, keep = pack_params(dims, sd, L)
-        N.check(lib.mvn_forward(dims, params, idx.data_ptr(), idx.stride(0), B, T, buf.struct,
+        N.check(lib.mvn_forward(dims, params, None if dense is not None else idx.data_ptr(),
+                                0 if dense is not None else idx.stride(0), B, T, buf.struct,
                                 out.data_ptr(), int(normalize), int(remove_last), int(save),
                                 _stream_ptr(dev)), "mvn_forward")
     buf._keep = keep  # parameter tensors stay alive until the kernels have run
@@ -113,7 +124,8 @@ class _WaveNetFunction(torch.autograd.Function):
         dims, names, idx, buf = ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf
         L = dims.layer_size * dims.stack_size
         C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
-        B, T = idx.shape
+        dense_in = idx.dim() == 3
+        B, T = (idx.shape[0], idx.shape[2]) if dense_in else idx.shape
         dev = idx.device
         sd = dict(zip(names, params))
         dout = dout.to(torch.float32).contiguous()
@@ -135,7 +147,8 @@ class _WaveNetFunction(torch.autograd.Function):
                               da1.data_ptr(), dlogit.data_ptr(),
                               None if dctx is None else dctx.data_ptr())
             params_c, pkeep = pack_params(dims, sd, L)
-            N.check(lib.mvn_backward(dims, params_c, g, idx.data_ptr(), idx.stride(0), B, T,
+            N.check(lib.mvn_backward(dims, params_c, g, None if dense_in else idx.data_ptr(),
+                                     0 if dense_in else idx.stride(0), B, T,
                                      buf.struct, bw, out.data_ptr(), dout.data_ptr(),
                                      int(ctx_.normalize), int(ctx_.remove_last), _stream_ptr(dev)),
                     "mvn_backward")
@@ -217,7 +230,9 @@ def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalize
     """WaveNet.forward.  NOTE the reference's inverted flag (wavenet.py:189-191):
     output_unnormalized=True returns PROBABILITIES.  ``context``: upsampled video
     (B, C, T) or None."""
-    idx = model._indices_of(audio)
+    idx = model._indices_of(audio, strict=False)
+    if idx is None:  # not one-hot: dense causal conv on the tensor itself
+        idx = audio.detach().to(torch.float32).contiguous()
     model.compute_output_size(audio)  # ValueError when T < RF, like the reference
     L = model.layer_size * model.stack_size
     names = decoder_param_names(L, with_context=context is not None)

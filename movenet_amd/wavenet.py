@@ -118,8 +118,10 @@ class WaveNet(nn.Module):
         return out
 
     # ---- helpers --------------------------------------------------------
-    def _indices_of(self, audio: torch.Tensor) -> torch.Tensor:
-        """(B,Q,T) one-hot -> (B,T) int32 on device (mvn_onehot_to_index)."""
+    def _indices_of(self, audio: torch.Tensor, strict: bool = True):
+        """(B,Q,T) one-hot -> (B,T) int32 on device (mvn_onehot_to_index).  A column that
+        is not one-hot: ValueError when ``strict`` (generation works on class indices),
+        else None (forward then takes the dense causal-conv path)."""
         _require_gpu(audio, "audio")
         if audio.dim() != 3 or audio.size(1) != self.input_channels:
             raise ValueError(f"audio must be (batch, {self.input_channels}, frames), "
@@ -131,6 +133,8 @@ class WaveNet(nn.Module):
             N.check(N.lib().mvn_onehot_to_index(x.data_ptr(), idx.data_ptr(), B, Q, T,
                                                 _stream_ptr(x.device)), "mvn_onehot_to_index")
         if B * T and int(idx.min().item()) < 0:
+            if not strict:
+                return None
             raise ValueError(
                 "movenet_amd.WaveNet expects one-hot audio (movenet/dataset.py:278-289); "
                 "a column of the input is not one-hot")

@@ -134,3 +134,28 @@ def test_config2_forward_vs_generator_logits_full_batch():
                       device=DEV)
     _, glog = g.teacher_forced(idx, logits_t0=rf)  # (B, T-rf, Q)
     assert rel_err(logits.permute(0, 2, 1).cpu(), glog.cpu()) < LOGIT_TOL
+
+
+def test_dense_non_one_hot_input_forward_backward():
+    """The reference's forward accepts any (B,Q,T) float tensor (its causal conv is a
+    dense Conv1d, modules.py:19-30); so does this one: dense MFMA path, checked against
+    the oracle with autograd."""
+    from oracle import wavenet_oracle as O
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=2, stack_size=2, input_channels=64, residual_channels=16, skip_channels=16)
+    sd = make_state_dict(**cfg, seed=4)
+    dims = O.Dims(**cfg)
+    torch.manual_seed(0)
+    x = torch.rand(2, 64, 300) - 0.3
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_o = O.forward(params, dims, x, output_unnormalized=False)
+    out_o.square().mean().backward()
+    m = _model(cfg, sd).train()
+    out = m(x.to(DEV), output_unnormalized=False)
+    assert rel_err(out.detach().cpu(), out_o.detach()) < LOGIT_TOL
+    out.square().mean().backward()
+    for k, p in m.named_parameters():
+        if params[k].grad is None:
+            assert p.grad is None, k
+        else:
+            assert rel_err(p.grad.cpu(), params[k].grad) < 3e-4, k
