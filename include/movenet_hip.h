@@ -272,6 +272,14 @@ int mvn_onehot_to_index(const float *onehot, int32_t *index, int batch, int clas
 int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, int batch,
                         int classes, int t_len, void *stream);
 
+/* mu-law companding either side of the model (movenet/dataset.py:278-289 encode ->
+ * one-hot; movenet/callbacks.py:66-76 argmax -> decode).  The reference calls torchaudio,
+ * which is absent offline and pinned by no fixture: formula of RESEARCH.md:156-163,
+ * PARITY UNPINNED.  Shipping indices instead of (B,Q,T) one-hot floats removes a
+ * 256x larger host->device copy. */
+int mvn_mu_law_encode(const float *x, int32_t *index, size_t n, int classes, void *stream);
+int mvn_mu_law_decode(const int32_t *index, float *x, size_t n, int classes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,9 +66,51 @@ __global__ void index_to_onehot_kernel(const int32_t *__restrict__ idx, int stri
   x[((size_t)b * Q + q) * T + t] = (idx[(size_t)b * stride + t] == q) ? 1.0f : 0.0f;
 }
 
+// mu-law companding, the formula the project states (RESEARCH.md:156-163) and
+// torchaudio.functional.mu_law_encoding/decoding implement (absent offline: UNPINNED):
+//   y = sign(x) ln(1 + mu|x|) / ln(1 + mu),  q = int((y + 1)/2 * mu + 0.5),  mu = Q - 1
+__global__ void mu_law_encode_kernel(const float *__restrict__ x, int32_t *__restrict__ q, size_t n,
+                                     int Q) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mu = (float)(Q - 1), v = x[i];
+  const float y = copysignf(log1pf(mu * fabsf(v)) / log1pf(mu), v);
+  q[i] = (int32_t)((y + 1.0f) / 2.0f * mu + 0.5f);
+}
+__global__ void mu_law_decode_kernel(const int32_t *__restrict__ q, float *__restrict__ x, size_t n,
+                                     int Q) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mu = (float)(Q - 1);
+  const float y = ((float)q[i] / mu) * 2.0f - 1.0f;
+  x[i] = copysignf((expf(fabsf(y) * log1pf(mu)) - 1.0f) / mu, y);
+}
+
 }  // namespace mvn
 
 extern "C" {
+
+int mvn_mu_law_encode(const float *x, int32_t *index, size_t n, int classes, void *stream) {
+  if (!x || !index || classes < 2) {
+    mvn::set_error("mvn_mu_law_encode: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (n == 0) return MVN_OK;
+  hipLaunchKernelGGL(mvn::mu_law_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, index, n, classes);
+  return mvn::check_hip(hipGetLastError(), "mu_law_encode");
+}
+
+int mvn_mu_law_decode(const int32_t *index, float *x, size_t n, int classes, void *stream) {
+  if (!x || !index || classes < 2) {
+    mvn::set_error("mvn_mu_law_decode: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (n == 0) return MVN_OK;
+  hipLaunchKernelGGL(mvn::mu_law_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, index, x, n, classes);
+  return mvn::check_hip(hipGetLastError(), "mu_law_decode");
+}
 
 int mvn_abi_version(void) { return MVN_ABI_VERSION; }
 const char *mvn_last_error(void) { return mvn::g_err; }

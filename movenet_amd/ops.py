@@ -152,7 +152,7 @@ class _WaveNetFunction(torch.autograd.Function):
                                      buf.struct, bw, out.data_ptr(), dout.data_ptr(),
                                      int(ctx_.normalize), int(ctx_.remove_last), _stream_ptr(dev)),
                     "mvn_backward")
-        ctx_.buf = None
+        # (buffers are released with the autograd node; a retained graph may run backward again)
         last = f"residual_conv_stack.conv_layers.{L - 1}.conv_residual."
         need = ctx_.needs_input_grad
         result = []
@@ -241,3 +241,26 @@ def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalize
     out = _WaveNetFunction.apply(model._dims, names, idx, bool(output_unnormalized),
                                  bool(remove_last), context, *params)
     return out if audio.dtype == torch.float32 else out.to(audio.dtype)
+
+
+def mu_law_encode(x: torch.Tensor, quantization_channels: int) -> torch.Tensor:
+    """float waveform in [-1, 1] (any shape, on the GPU) -> int32 class indices."""
+    _require_gpu(x, "waveform")
+    x = x.detach().to(torch.float32).contiguous()
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().mvn_mu_law_encode(x.data_ptr(), out.data_ptr(), x.numel(),
+                                          quantization_channels, _stream_ptr(x.device)),
+                "mvn_mu_law_encode")
+    return out
+
+
+def mu_law_decode(index: torch.Tensor, quantization_channels: int) -> torch.Tensor:
+    _require_gpu(index, "indices")
+    index = index.detach().to(torch.int32).contiguous()
+    out = torch.empty(index.shape, dtype=torch.float32, device=index.device)
+    with torch.cuda.device(index.device):
+        N.check(N.lib().mvn_mu_law_decode(index.data_ptr(), out.data_ptr(), index.numel(),
+                                          quantization_channels, _stream_ptr(index.device)),
+                "mvn_mu_law_decode")
+    return out

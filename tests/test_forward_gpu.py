@@ -159,3 +159,43 @@ def test_dense_non_one_hot_input_forward_backward():
             assert p.grad is None, k
         else:
             assert rel_err(p.grad.cpu(), params[k].grad) < 3e-4, k
+
+
+def test_mu_law_kernels():
+    """Formula of RESEARCH.md:156-163 (torchaudio is absent: parity UNPINNED).  Property
+    checks: every class index survives decode -> encode; encode is monotone; the GPU
+    kernels agree with the host formulas used by the synthetic data path."""
+    from movenet_amd.dataset import mu_law_decoding, mu_law_encoding
+    from movenet_amd.ops import mu_law_decode, mu_law_encode
+    for Q in (64, 256):
+        q = torch.arange(Q, dtype=torch.int32, device=DEV)
+        x = mu_law_decode(q, Q)
+        assert torch.equal(mu_law_encode(x, Q), q)
+        assert x.min().item() == -1.0 and abs(x.max().item() - 1.0) < 1e-6
+        assert torch.allclose(x.cpu(), mu_law_decoding(q.cpu().long(), Q), atol=1e-6)
+        w = torch.linspace(-1, 1, 100001, device=DEV)
+        e = mu_law_encode(w, Q)
+        assert e.min().item() == 0 and e.max().item() == Q - 1 and torch.all(e[1:] >= e[:-1])
+        assert (e.cpu().long() != mu_law_encoding(w.cpu(), Q)).float().mean().item() < 1e-3
+
+
+def test_config2_full_size_training_step_properties():
+    """BASELINE config 2 at its full size (B=16, T=16000): outputs are distributions,
+    the loss sits at ln 256 (Q2), the gradient is linear in the upstream gradient and
+    zero upstream gradient gives zero parameter gradients."""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    m = _model(cfg, make_state_dict(**cfg, seed=0)).train()
+    x = one_hot(synthetic_indices(16, 16000, 256, 1234).to(DEV), 256)
+    out = m(x)
+    assert out.shape == (16, 256, 16000 - 3072)
+    assert torch.allclose(out.sum(1), torch.ones_like(out.sum(1)), atol=1e-5)
+    target = x[:, :, 3072:].argmax(1)
+    loss = F.cross_entropy(out, target)
+    assert abs(loss.item() - np.log(256)) < 1e-3
+    w = m.dense_conv.conv2.weight
+    g1, = torch.autograd.grad(loss, w, retain_graph=True)
+    g2, = torch.autograd.grad(2.5 * loss, w, retain_graph=True)
+    assert rel_err(g2.cpu(), (2.5 * g1).cpu()) < 1e-4        # atomics: last bits may differ
+    g0, = torch.autograd.grad((out * 0).sum(), m.causal_conv.conv.weight)
+    assert torch.count_nonzero(g0).item() == 0

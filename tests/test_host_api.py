@@ -51,3 +51,22 @@ def test_cpu_tensors_are_refused():
         m.generate(x, n_samples=20, temperature=0.0)
     with pytest.raises(RuntimeError, match="MI355X"):
         m(x)
+
+
+def test_reference_checkpoint_flavours_load(tmp_path):
+    """Plain state_dict, DDP `module.` prefix, Lightning `{"state_dict": {"model.…"}}`."""
+    from movenet_amd.checkpoint import load_into, load_state_dict_file
+    cfg = dict(layer_size=2, stack_size=2, input_channels=16, residual_channels=8, skip_channels=8)
+    sd = make_state_dict(**cfg, seed=3)
+    torch.save(sd, tmp_path / "model.pth")
+    torch.save({"module." + k: v for k, v in sd.items()}, tmp_path / "ddp.pth")
+    torch.save({"epoch": 3, "state_dict": {"model." + k: v for k, v in sd.items()}}, tmp_path / "pl.ckpt")
+    for name in ("model.pth", "ddp.pth", "pl.ckpt"):
+        got = load_state_dict_file(tmp_path / name)
+        assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+        m = W.WaveNet(**cfg)
+        load_into(m, tmp_path / name)
+        assert torch.equal(m.state_dict()["dense_conv.conv2.bias"], sd["dense_conv.conv2.bias"])
+    torch.save([1, 2, 3], tmp_path / "junk.pth")
+    with pytest.raises(ValueError):
+        load_state_dict_file(tmp_path / "junk.pth")
