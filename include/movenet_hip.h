@@ -158,8 +158,10 @@ int mvn_transpose_context(const float *ctx, int ctx_ld, int batch, int channels,
  * (batch, channels, Tp) with Tp = mvn_padded_len(T) and column t = input time
  * t; layer l's input is valid for t >= A_l (A_0 = 0, A_{l+1} = A_l + d_l), so
  * the reference's right-aligned slices (modules.py:84, :91) become "same t".
- * Skip/head tensors are (batch, channels, Sp), Sp = mvn_padded_len(S),
- * S = T - RF + 1, column s = time RF-1+s.
+ * Skip/head tensors are (batch, channels, Sp), Sp = mvn_padded_len(S + 3),
+ * S = T - RF + 1; the column of time t is t - ((RF-1) & ~3), i.e. the S valid
+ * columns start at column (RF-1) & 3, so that column == t (mod 4) and 16-byte
+ * accesses stay aligned on both time axes.
  * ------------------------------------------------------------------------ */
 int mvn_padded_len(int n); /* n rounded up to a multiple of 64 */
 

@@ -17,6 +17,15 @@ struct Act {  // (B, ch, ld) view
   }
 };
 
+// Masked operand load WITHOUT a branch: the address is clamped into [lo, hi) and the value
+// selected afterwards.  `cond ? *p : 0` makes hipcc wrap every element in its own exec-mask
+// region (s_and_saveexec / s_cbranch_execz), which made operand staging 1.5-2x slower.
+__device__ __forceinline__ float ld_masked(const Act &a, int b, int ch, int t, int lo, int hi) {
+  const int tc = min(max(t, lo), hi - 1);
+  const float v = *a.at(b, ch, tc);
+  return (t >= lo && t < hi) ? v : 0.f;
+}
+
 // accumulator register r of lane `lane` -> row inside a 32x32 MFMA tile
 __device__ __forceinline__ int acc_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -32,7 +41,10 @@ template <class Op>
 __global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
   __shared__ float Ws[2][GX_KC][64];
   __shared__ float Xs[2][GX_KC][256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction; readfirstlane lets the compiler keep row/k indices (and the
+  // operand accessors' branches on them) on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, mb = blockIdx.y;
   const int t0 = op.t_begin + blockIdx.x * 256;
   const int nchunk = (op.K + GX_KC - 1) / GX_KC;
@@ -49,13 +61,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
   auto gload = [&](int c) {
     const int k0 = c * GX_KC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + (tid & 63), k0 + (tid >> 6) + 4 * j);
+    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + lane, k0 + wave + 4 * j);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xreg[j] = op.x(b, k0 + j, t0 + tid);
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Ws[buf][(tid >> 6) + 4 * j][tid & 63] = wreg[j];
+    for (int j = 0; j < 4; ++j) Ws[buf][wave + 4 * j][lane] = wreg[j];
 #pragma unroll
     for (int j = 0; j < 16; ++j) Xs[buf][j][tid] = xreg[j];
   };
@@ -88,6 +100,96 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
   }
 }
 
+// Same product, epilogue through LDS: the accumulators are written to a 32-row x
+// 256-column stage (the idle X buffers), then every thread takes whole float4 column
+// groups of whole rows -- 16-byte, row-contiguous global accesses, no 64-value register
+// epilogue (which spilled ~100 VGPRs to scratch in the residual/skip and dz ops).  Tiles
+// start at a multiple of 4 so that those accesses are aligned; Op::x must return 0 for
+// t < t_begin and Op::store4(b, m, t, v) masks columns outside [t_begin, t_end).
+typedef float4 f4;
+
+template <class Op>
+__global__ __launch_bounds__(256, 2) void gemm_wx_staged_kernel(Op op) {
+  __shared__ float Ws[2][GX_KC][64];
+  __shared__ __attribute__((aligned(16))) float Xs[2][GX_KC][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction; readfirstlane lets the compiler keep row/k indices (and the
+  // operand accessors' branches on them) on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, mb = blockIdx.y;
+  const int t0 = (op.t_begin & ~3) + blockIdx.x * 256;
+  const int nchunk = (op.K + GX_KC - 1) / GX_KC;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float wreg[4], xreg[16];
+  auto gload = [&](int c) {
+    const int k0 = c * GX_KC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + lane, k0 + wave + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xreg[j] = op.x(b, k0 + j, t0 + tid);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ws[buf][wave + 4 * j][lane] = wreg[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Xs[buf][j][tid] = xreg[j];
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < GX_KC / 2; ++kk) {
+      const int kr = 2 * kk + (lane >> 5);
+      const float a0 = Ws[buf][kr][lane & 31], a1 = Ws[buf][kr][32 + (lane & 31)];
+      const float b0 = Xs[buf][kr][64 * wave + (lane & 31)];
+      const float b1 = Xs[buf][kr][64 * wave + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  float *stage = &Xs[0][0][0];  // [32][256]
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[acc_row(r, lane) * 256 + 64 * wave + 32 * ni + (lane & 31)] = acc[mi][ni][r];
+    __syncthreads();
+    const int c4 = tid & 63, t = t0 + 4 * c4;
+    if (t < op.t_end) {
+      for (int j = 0; j < 8; ++j) {
+        const int row = wave + 4 * j;
+        const f4 v = *(const f4 *)&stage[row * 256 + 4 * c4];
+        op.store4(b, mb * 64 + 32 * mi + row, t, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// column mask helpers for store4: all four columns inside [lo, hi)?
+__device__ __forceinline__ bool cols_full(int t, int lo, int hi) { return t >= lo && t + 3 < hi; }
+__device__ __forceinline__ float f4_get(const f4 &v, int e) {
+  return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+
 // ======================================================================
 // wgrad: dW(m,n) += sum_{b,t} A(b,m,t) * X(b,n,t); block tile 64 x 64, each
 // wave one 32x32 MFMA tile, K = time.  Grid: (time chunks * B, M/64 * N/64).
@@ -104,7 +206,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int ch
                                                       float *__restrict__ bias_part, int m_rows64) {
   __shared__ float As[2][64][WG_T + 1];
   __shared__ float Xs[2][64][WG_T + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction; readfirstlane lets the compiler keep row/k indices (and the
+  // operand accessors' branches on them) on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
   const int mi = wave >> 1, ni = wave & 1;
@@ -119,13 +224,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int ch
 #pragma unroll
   for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
   auto gload = [&](int t0) {
-    const int t = t0 + lane;
-    const bool ok = t < te;
+    const int t = min(t0 + lane, te - 1);  // clamped: loads are unconditional, the tail is
+    const bool ok = t0 + lane < te;         // zeroed by a select (no exec-mask branches)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int row = wave + 4 * j;
-      areg[j] = ok ? op.a(b, mblk * 64 + row, t) : 0.f;
-      xreg[j] = ok ? op.x(b, nblk * 64 + row, t) : 0.f;
+      const float av = op.a(b, mblk * 64 + row, t), xv = op.x(b, nblk * 64 + row, t);
+      areg[j] = ok ? av : 0.f;
+      xreg[j] = ok ? xv : 0.f;
     }
   };
   auto lstore = [&](int buf) {
@@ -207,6 +313,14 @@ static void launch_gemm(const Op &op, int m_rows, int batch, hipStream_t s) {
 }
 
 // bias_scratch: >= chunks*batch*64*ceil(m_rows/64) floats, or NULL when the op has no bias
+template <class Op>
+static void launch_gemm_staged(const Op &op, int m_rows, int batch, hipStream_t s) {
+  const int nt = op.t_end - (op.t_begin & ~3);
+  if (op.t_end <= op.t_begin || batch <= 0) return;
+  dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
+  hipLaunchKernelGGL(gemm_wx_staged_kernel<Op>, grid, dim3(256), 0, s, op);
+}
+
 template <class Op>
 static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, float *bias_scratch,
                          hipStream_t s) {

@@ -30,7 +30,8 @@ namespace mvn {
 // context convolutions (modules.py:58-63, :75-77), their biases are added in the epilogue.
 // BUILD DEFINITION: the context is aligned on the same absolute time as f/g (the
 // reference raises a shape error here).
-struct FgOp {
+template <bool HAS_CTX>
+struct FgOpT {
   int K, t_begin, t_end, C, d;
   const float *wf, *wg;  // (C, C, 2)
   const float *wcf, *wcg, *bcf, *bcg;  // (C, C, 1), (C)
@@ -40,14 +41,14 @@ struct FgOp {
   __device__ __forceinline__ float w(int m, int k) const {
     const int r = m & 63, c = (m >> 6) * 32 + (r & 31);
     if (c >= C || k >= K) return 0.f;
-    if (k >= 2 * C) return (r < 32 ? wcf : wcg)[(size_t)c * C + (k - 2 * C)];
+    if (HAS_CTX && k >= 2 * C) return (r < 32 ? wcf : wcg)[(size_t)c * C + (k - 2 * C)];
     const int tap = k >= C, kc = k - tap * C;
     const float *src = r < 32 ? wf : wg;
     return src[((size_t)c * C + kc) * 2 + tap];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
     if (k >= K || t >= t_end) return 0.f;
-    if (k >= 2 * C) return *ctx.at(b, k - 2 * C, t);
+    if (HAS_CTX && k >= 2 * C) return *ctx.at(b, k - 2 * C, t);
     return k < C ? *xin.at(b, k, t - d) : *xin.at(b, k - C, t);  // t >= t_begin >= d
   }
   __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &f,
@@ -57,7 +58,7 @@ struct FgOp {
       const int c = mb * 32 + acc_row(r, lane);
       if (c < C) {
         float fv = f[r], gv = g[r];
-        if (ctx.p) {
+        if (HAS_CTX) {
           fv += bcf[c];
           gv += bcg[c];
         }
@@ -75,7 +76,7 @@ struct FgOp {
 // F2: residual 1x1 (+bias +input) and skip 1x1 (+bias, accumulated for t >= t_skip0).
 // Rows: [0,C) residual channels, [C, C+Kc) skip channels.
 struct RsOp {
-  int K, t_begin, t_end, C, Kc, t_skip0;
+  int K, t_begin, t_end, C, Kc, t_skip0, t_base;  // skip column of time t = t - t_base
   const float *wr, *br, *ws, *bs;  // (C,C,1),(C),(Kc,C,1),(Kc)
   Act z, xin, xout, skip;
   int first_layer;  // skip is overwritten instead of accumulated
@@ -86,47 +87,41 @@ struct RsOp {
     return 0.f;
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    return (k < C && t < t_end) ? *z.at(b, k, t) : 0.f;
+    return (k < C && t >= t_begin && t < t_end) ? *z.at(b, k, t) : 0.f;
   }
-  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
     if (m < C) {
-      if (xout.p) *xout.at(b, m, t) = (v + br[m]) + *xin.at(b, m, t);
-    } else if (m < C + Kc && t >= t_skip0) {
-      float *s = skip.at(b, m - C, t - t_skip0);
-      const float add = v + bs[m - C];
-      *s = first_layer ? add : *s + add;
-    }
-  }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
-                                           const f32x16 &a1) const {
-    const int m0 = mb * 64 + 4 * (lane >> 5);
-    if (m0 + 64 <= C) {  // the whole 64-row block is residual rows (block-uniform)
       if (!xout.p) return;
-      const float *xi = xin.at(b, m0, t);
-      float *xo = xout.at(b, m0, t);
+      const float bias = br[m];
+      const float *xi = xin.at(b, m, t);
+      float *xo = xout.at(b, m, t);
+      if (cols_full(t, t_begin, t_end)) {
+        const f4 xv = *(const f4 *)xi;
+        *(f4 *)xo = f4{(v.x + bias) + xv.x, (v.y + bias) + xv.y, (v.z + bias) + xv.z,
+                       (v.w + bias) + xv.w};
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dm = (r & 3) + 8 * (r >> 2);
-        xo[(size_t)dm * xout.ld] = (a0[r] + br[m0 + dm]) + xi[(size_t)dm * xin.ld];
-        xo[(size_t)(dm + 32) * xout.ld] = (a1[r] + br[m0 + 32 + dm]) + xi[(size_t)(dm + 32) * xin.ld];
+        for (int e = 0; e < 4; ++e)
+          if (t + e >= t_begin && t + e < t_end) xo[e] = (f4_get(v, e) + bias) + xi[e];
       }
-    } else if (mb * 64 >= C && mb * 64 + 64 <= C + Kc) {  // the whole block is skip rows
-      if (t < t_skip0) return;
-      const int k0 = m0 - C;
-      float *sp = skip.at(b, k0, t - t_skip0);
+    } else if (m < C + Kc) {
+      const int k = m - C, lo = max(t_begin, t_skip0);
+      const float bias = bs[k];
+      float *sp = skip.at(b, k, t - t_base);
+      if (cols_full(t, lo, t_end)) {
+        f4 o = f4{v.x + bias, v.y + bias, v.z + bias, v.w + bias};
+        if (!first_layer) {
+          const f4 old = *(const f4 *)sp;
+          o = f4{old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w};
+        }
+        *(f4 *)sp = o;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dm = (r & 3) + 8 * (r >> 2);
-        float *s0 = sp + (size_t)dm * skip.ld, *s1 = sp + (size_t)(dm + 32) * skip.ld;
-        const float v0 = a0[r] + bs[k0 + dm], v1 = a1[r] + bs[k0 + 32 + dm];
-        *s0 = first_layer ? v0 : *s0 + v0;
-        *s1 = first_layer ? v1 : *s1 + v1;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-        one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+        for (int e = 0; e < 4; ++e)
+          if (t + e >= lo && t + e < t_end) {
+            const float add = f4_get(v, e) + bias;
+            sp[e] = first_layer ? add : sp[e] + add;
+          }
       }
     }
   }
@@ -138,33 +133,40 @@ enum { OUT_BIAS = 0, OUT_BIAS_LRELU = 1, OUT_MUL_DLRELU = 2 };
 template <int IN, int OUT, bool TRANSPOSED>
 struct DenseOp {
   int K, t_begin, t_end, M;
-  const float *wmat;  // (rows, cols, 1): W[m][k] = TRANSPOSED ? wmat[k*M_src + m] : wmat[m*K + k]
+  const float *wmat;  // (rows, cols, 1): W[m][k] = TRANSPOSED ? wmat[k*ldw + m] : wmat[m*ldw + k]
   int ldw;            // row length of wmat
   const float *bias;
   Act xin, yout, ref;  // ref: activation whose sign gates the lrelu derivative
   int t_out_end;       // columns >= this are not stored (remove_last)
+  int aligned_out;     // yout rows are 16-byte aligned at multiples of 4
   __device__ __forceinline__ float w(int m, int k) const {
     if (m >= M || k >= K) return 0.f;
     return TRANSPOSED ? wmat[(size_t)k * ldw + m] : wmat[(size_t)m * ldw + k];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    if (k >= K || t >= t_end) return 0.f;
+    if (k >= K || t < t_begin || t >= t_end) return 0.f;
     const float v = *xin.at(b, k, t);
     return IN == IN_LRELU ? leaky(v) : v;
   }
-  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
-    if (m >= M || t >= t_out_end) return;
-    if (OUT == OUT_BIAS) v = v + bias[m];
-    if (OUT == OUT_BIAS_LRELU) v = leaky(v + bias[m]);
-    if (OUT == OUT_MUL_DLRELU) v = v * (*ref.at(b, m, t) > 0.f ? 1.0f : kLeakySlope);
-    *yout.at(b, m, t) = v;
+  __device__ __forceinline__ float map(float v, float bv, float refv) const {
+    if (OUT == OUT_BIAS) return v + bv;
+    if (OUT == OUT_BIAS_LRELU) return leaky(v + bv);
+    return v * (refv > 0.f ? 1.0f : kLeakySlope);
   }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
-                                           const f32x16 &a1) const {
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+    if (m >= M) return;
+    const float bv = OUT == OUT_MUL_DLRELU ? 0.f : bias[m];
+    float *yo = yout.at(b, m, t);
+    const float *rp = OUT == OUT_MUL_DLRELU ? ref.at(b, m, t) : nullptr;
+    if (aligned_out && cols_full(t, t_begin, t_out_end)) {
+      f4 r = f4{0.f, 0.f, 0.f, 0.f};
+      if (OUT == OUT_MUL_DLRELU) r = *(const f4 *)rp;
+      *(f4 *)yo = f4{map(v.x, bv, r.x), map(v.y, bv, r.y), map(v.z, bv, r.z), map(v.w, bv, r.w)};
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      for (int e = 0; e < 4; ++e)
+        if (t + e >= t_begin && t + e < t_out_end)
+          yo[e] = map(f4_get(v, e), bv, OUT == OUT_MUL_DLRELU ? rp[e] : 0.f);
     }
   }
 };
@@ -183,17 +185,19 @@ struct CausalOp {
     return cw[((size_t)m * Q + q) * 2 + tap];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    if (k >= 2 * Q || t >= t_end) return 0.f;
+    if (k >= 2 * Q || t < t_begin || t >= t_end) return 0.f;
     if (k < Q) return t > 0 ? *audio.at(b, k, t - 1) : 0.f;
     return *audio.at(b, k - Q, t);
   }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
-                                           const f32x16 &a1) const {
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+    if (m >= C) return;
+    float *o = x0.at(b, m, t);
+    if (cols_full(t, t_begin, t_end)) {
+      *(f4 *)o = v;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m0 = mb * 64 + acc_row(r, lane), m1 = m0 + 32;
-      if (m0 < C) *x0.at(b, m0, t) = a0[r];
-      if (m1 < C) *x0.at(b, m1, t) = a1[r];
+      for (int e = 0; e < 4; ++e)
+        if (t + e >= t_begin && t + e < t_end) o[e] = f4_get(v, e);
     }
   }
 };
@@ -220,7 +224,7 @@ struct WgCausalOp {
 // ---- backward data-gradient ops ------------------------------------------
 // B3: dz = Wr^T dxo + Ws^T dskip ; df = dz*sg*(1-th^2) ; dg = dz*th*sg*(1-sg)
 struct DzOp {
-  int K, t_begin, t_end, C, Kc, t_skip0;
+  int K, t_begin, t_end, C, Kc, t_skip0, t_base;
   const float *wr, *ws;
   Act dxo, dskip, th, sg, dfg;  // dxo.p == NULL for the last layer (output unused)
   __device__ __forceinline__ float w(int m, int k) const {
@@ -230,40 +234,29 @@ struct DzOp {
     return 0.f;
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    if (t >= t_end) return 0.f;
+    if (t < t_begin || t >= t_end) return 0.f;
     if (k < C) return dxo.p ? *dxo.at(b, k, t) : 0.f;
-    if (k < C + Kc) return t >= t_skip0 ? *dskip.at(b, k - C, t - t_skip0) : 0.f;
+    if (k < C + Kc) return t >= t_skip0 ? *dskip.at(b, k - C, t - t_base) : 0.f;
     return 0.f;
   }
-  __device__ __forceinline__ void one(int b, int m, int t, float dz) const {
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &dz) const {
     if (m >= C) return;
-    const float tv = *th.at(b, m, t), sv = *sg.at(b, m, t);
-    *dfg.at(b, m, t) = dz * sv * (1.0f - tv * tv);
-    *dfg.at(b, C + m, t) = dz * tv * sv * (1.0f - sv);
-  }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
-                                           const f32x16 &a1) const {
-    const int m0 = mb * 64 + 4 * (lane >> 5);
-    if (mb * 64 + 64 <= C) {  // every row of the block is a real channel (block-uniform)
-      const float *tp = th.at(b, m0, t), *sp = sg.at(b, m0, t);
-      float *df = dfg.at(b, m0, t), *dg = dfg.at(b, C + m0, t);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const size_t dm = (size_t)((r & 3) + 8 * (r >> 2) + 32 * hh);
-          const float dz = hh ? a1[r] : a0[r];
-          const float tv = tp[dm * th.ld], sv = sp[dm * sg.ld];
-          df[dm * dfg.ld] = dz * sv * (1.0f - tv * tv);
-          dg[dm * dfg.ld] = dz * tv * sv * (1.0f - sv);
-        }
-      }
+    const float *tp = th.at(b, m, t), *sp = sg.at(b, m, t);
+    float *df = dfg.at(b, m, t), *dg = dfg.at(b, C + m, t);
+    if (cols_full(t, t_begin, t_end)) {
+      const f4 tv = *(const f4 *)tp, sv = *(const f4 *)sp;
+      *(f4 *)df = f4{dz.x * sv.x * (1.0f - tv.x * tv.x), dz.y * sv.y * (1.0f - tv.y * tv.y),
+                     dz.z * sv.z * (1.0f - tv.z * tv.z), dz.w * sv.w * (1.0f - tv.w * tv.w)};
+      *(f4 *)dg = f4{dz.x * tv.x * sv.x * (1.0f - sv.x), dz.y * tv.y * sv.y * (1.0f - sv.y),
+                     dz.z * tv.z * sv.z * (1.0f - sv.z), dz.w * tv.w * sv.w * (1.0f - sv.w)};
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-        one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
-      }
+      for (int e = 0; e < 4; ++e)
+        if (t + e >= t_begin && t + e < t_end) {
+          const float d = f4_get(dz, e), tv = tp[e], sv = sp[e];
+          df[e] = d * sv * (1.0f - tv * tv);
+          dg[e] = d * tv * sv * (1.0f - sv);
+        }
     }
   }
 };
@@ -282,27 +275,33 @@ struct DxOp {
     return src[((size_t)o * C + m) * 2 + tap];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    if (k >= 4 * C || t >= t_end) return 0.f;
+    if (k >= 4 * C || t < t_begin || t >= t_end) return 0.f;
     if (k < 2 * C) return t >= t_lo ? *dfg.at(b, k, t) : 0.f;
     return t + d < t_end ? *dfg.at(b, k - 2 * C, t + d) : 0.f;
   }
-  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
     if (m >= C) return;
-    if (dxo.p && t >= t_lo) v += *dxo.at(b, m, t);
-    *dxi.at(b, m, t) = v;
-  }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
-                                           const f32x16 &a1) const {
+    float *o = dxi.at(b, m, t);
+    const float *po = dxo.p ? dxo.at(b, m, t) : nullptr;
+    if (cols_full(t, t_begin, t_end) && (!po || t >= t_lo)) {
+      f4 r = v;
+      if (po) {
+        const f4 u = *(const f4 *)po;
+        r = f4{v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w};
+      }
+      *(f4 *)o = r;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      for (int e = 0; e < 4; ++e)
+        if (t + e >= t_begin && t + e < t_end)
+          o[e] = f4_get(v, e) + ((po && t + e >= t_lo) ? po[e] : 0.f);
     }
   }
 };
 
 // dWf/dWg: A = dfg rows (f | g), X = layer input (past | cur) -> (C,C,2) taps
-struct WgFgOp {
+template <bool HAS_CTX>
+struct WgFgOpT {
   int t_begin, t_end, C, d;
   Act dfg, xin, ctx;  // ctx.p == NULL: audio only
   float *dwf, *dwg, *dwcf, *dwcg, *dbcf, *dbcg;
@@ -310,14 +309,14 @@ struct WgFgOp {
     return m < 2 * C ? *dfg.at(b, m, t) : 0.f;
   }
   __device__ __forceinline__ float x(int b, int n, int t) const {
-    if (n >= 2 * C) return (ctx.p && n < 3 * C) ? *ctx.at(b, n - 2 * C, t) : 0.f;
+    if (n >= 2 * C) return (HAS_CTX && n < 3 * C) ? *ctx.at(b, n - 2 * C, t) : 0.f;
     return n < C ? *xin.at(b, n, t - d) : *xin.at(b, n - C, t);
   }
   __device__ __forceinline__ float *dw(int m, int n) const {
     if (m >= 2 * C) return nullptr;
     const int o = m < C ? m : m - C;
     if (n >= 2 * C) {
-      if (!ctx.p || n >= 3 * C) return nullptr;
+      if (!HAS_CTX || n >= 3 * C) return nullptr;
       return (m < C ? dwcf : dwcg) + (size_t)o * C + (n - 2 * C);
     }
     float *base = m < C ? dwf : dwg;
@@ -325,7 +324,7 @@ struct WgFgOp {
     return base + ((size_t)o * C + c) * 2 + tap;
   }
   __device__ __forceinline__ float *db(int m) const {
-    if (!ctx.p || m >= 2 * C) return nullptr;
+    if (!HAS_CTX || m >= 2 * C) return nullptr;
     return m < C ? dbcf + m : dbcg + (m - C);
   }
 };
@@ -340,27 +339,33 @@ struct DctxOp {
     return k < C ? wcf[(size_t)k * C + m] : wcg[(size_t)(k - C) * C + m];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    return (k < 2 * C && t < t_end) ? *dfg.at(b, k, t) : 0.f;
+    return (k < 2 * C && t >= t_begin && t < t_end) ? *dfg.at(b, k, t) : 0.f;
   }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
-                                           const f32x16 &a1) const {
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+    if (m >= C) return;
+    float *o = dctx.at(b, m, t);
+    if (cols_full(t, t_begin, t_end)) {
+      const f4 u = *(const f4 *)o;
+      *(f4 *)o = f4{u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m0 = mb * 64 + acc_row(r, lane), m1 = m0 + 32;
-      if (m0 < C) *dctx.at(b, m0, t) += a0[r];
-      if (m1 < C) *dctx.at(b, m1, t) += a1[r];
+      for (int e = 0; e < 4; ++e)
+        if (t + e >= t_begin && t + e < t_end) o[e] += f4_get(v, e);
     }
   }
 };
 
 // dWr,dbr,dWs,dbs: A = [dxo ; dskip], X = z = th*sg
 struct WgRsOp {
-  int t_begin, t_end, C, Kc, t_skip0;
+  int t_begin, t_end, C, Kc, t_skip0, t_base;
   Act dxo, dskip, th, sg;  // dxo.p == NULL for the last layer
   float *dwr, *dbr, *dws, *dbs;
   __device__ __forceinline__ float a(int b, int m, int t) const {
-    if (m < C) return dxo.p ? *dxo.at(b, m, t) : 0.f;
-    if (m < C + Kc) return t >= t_skip0 ? *dskip.at(b, m - C, t - t_skip0) : 0.f;
+    if (m < C) return dxo.p ? *dxo.at(b, m, t) : 0.f;  // the wgrad kernel passes t < t_end only
+    if (m < C + Kc) {
+      const int lo = max(t_begin, t_skip0);
+      return ld_masked(dskip, b, m - C, t - t_base, lo - t_base, t_end - t_base);
+    }
     return 0.f;
   }
   __device__ __forceinline__ float x(int b, int n, int t) const {
@@ -449,11 +454,11 @@ __global__ void softmax_kernel(float *__restrict__ y, int Q, int S) {
 
 // dlogit = normalize ? p * (dout - sum_q dout*p) : dout ; zero for columns >= S_out
 __global__ void softmax_bwd_kernel(const float *__restrict__ p, const float *__restrict__ dout,
-                                   Act dlogit, int Q, int S_out, int S, int normalize) {
+                                   Act dlogit, int Q, int S_out, int S, int normalize, int pad) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (s >= S) return;
   if (s >= S_out) {
-    for (int q = 0; q < Q; ++q) *dlogit.at(b, q, s) = 0.f;
+    for (int q = 0; q < Q; ++q) *dlogit.at(b, q, s + pad) = 0.f;
     return;
   }
   const float *pc = p + (size_t)b * Q * S_out + s, *dc = dout + (size_t)b * Q * S_out + s;
@@ -462,7 +467,7 @@ __global__ void softmax_bwd_kernel(const float *__restrict__ p, const float *__r
     for (int q = 0; q < Q; ++q) dot += dc[(size_t)q * S_out] * pc[(size_t)q * S_out];
   for (int q = 0; q < Q; ++q) {
     const float d = dc[(size_t)q * S_out];
-    *dlogit.at(b, q, s) = normalize ? pc[(size_t)q * S_out] * (d - dot) : d;
+    *dlogit.at(b, q, s + pad) = normalize ? pc[(size_t)q * S_out] * (d - dot) : d;
   }
 }
 
@@ -490,6 +495,9 @@ __global__ void ring_fill_kernel(const float *__restrict__ acts, long long act_s
 // ======================================================================
 struct Geometry {
   int L, C, Kc, Q, T, Tp, S, Sp, rf;
+  int pad, t_base;  // skip/head tensors: column of time t = t - t_base, t_base = (RF-1) & ~3,
+                    // so that column == t (mod 4): float4 accesses stay aligned; the first
+                    // valid column is pad = (RF-1) & 3
   long long act;   // floats per (B,C,Tp) tensor
   long long skp;   // floats per (B,Kc,Sp)
   long long hid;   // floats per (B,Q,Sp)
@@ -511,7 +519,9 @@ static int make_geometry(const mvn_dims *d, int batch, int t_len, Geometry &g) {
   g.S = mvn_output_size(d, t_len);
   if (g.S < 0) return g.S;
   g.Tp = mvn_padded_len(t_len);
-  g.Sp = mvn_padded_len(g.S);
+  g.pad = (g.rf - 1) & 3;
+  g.t_base = (g.rf - 1) - g.pad;
+  g.Sp = mvn_padded_len(g.S + 3);
   g.act = (long long)batch * g.C * g.Tp;
   g.skp = (long long)batch * g.Kc * g.Sp;
   g.hid = (long long)batch * g.Q * g.Sp;
@@ -554,7 +564,7 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     c0.K = 2 * Q; c0.t_begin = 0; c0.t_end = T; c0.C = C; c0.Q = Q; c0.cw = p->causal_w;
     c0.audio = act_view(const_cast<float *>(buf->dense_audio), batch, Q, buf->dense_ld);
     c0.x0 = x0;
-    launch_gemm(c0, C, batch, s);
+    launch_gemm_staged(c0, C, batch, s);
   } else {
     hipLaunchKernelGGL(embed_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, p->causal_w,
                        index, index_stride, x0, C, Q, T);
@@ -574,38 +584,44 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     const int src = save ? l : (l & 1), dst = save ? l + 1 : ((l + 1) & 1);
     Act xin = act_view(buf->acts + (size_t)src * g.act, batch, C, g.Tp);
     Act xout = act_view(buf->acts + (size_t)dst * g.act, batch, C, g.Tp);
-    FgOp f;
-    f.K = has_ctx ? 3 * C : 2 * C; f.t_begin = A + d; f.t_end = T; f.C = C; f.d = d;
-    f.wf = p->filter_w[l]; f.wg = p->gate_w[l];
-    f.wcf = has_ctx ? p->ctx_filter_w[l] : nullptr; f.wcg = has_ctx ? p->ctx_gate_w[l] : nullptr;
-    f.bcf = has_ctx ? p->ctx_filter_b[l] : nullptr; f.bcg = has_ctx ? p->ctx_gate_b[l] : nullptr;
-    f.ctx = ctxv;
-    f.xin = xin; f.z = zv;
-    f.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
-    f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
-    launch_gemm(f, 2 * ((C + 31) / 32 * 32), batch, s);
+    auto run_fg = [&](auto f) {
+      f.K = has_ctx ? 3 * C : 2 * C; f.t_begin = A + d; f.t_end = T; f.C = C; f.d = d;
+      f.wf = p->filter_w[l]; f.wg = p->gate_w[l];
+      f.wcf = has_ctx ? p->ctx_filter_w[l] : nullptr; f.wcg = has_ctx ? p->ctx_gate_w[l] : nullptr;
+      f.bcf = has_ctx ? p->ctx_filter_b[l] : nullptr; f.bcg = has_ctx ? p->ctx_gate_b[l] : nullptr;
+      f.ctx = ctxv;
+      f.xin = xin; f.z = zv;
+      f.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+      f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+      launch_gemm(f, 2 * ((C + 31) / 32 * 32), batch, s);
+    };
+    if (has_ctx) run_fg(FgOpT<true>()); else run_fg(FgOpT<false>());
     RsOp r;
     r.K = C; r.t_begin = A + d; r.t_end = T; r.C = C; r.Kc = Kc; r.t_skip0 = t_skip0;
+    r.t_base = g.t_base;
     r.wr = p->residual_w[l]; r.br = p->residual_b[l]; r.ws = p->skip_w[l]; r.bs = p->skip_b[l];
     r.z = zv; r.xin = xin; r.xout = xout; r.skip = skipv; r.first_layer = (l == 0);
     if (l == g.L - 1) r.xout.p = nullptr;  // the last residual output is never used
-    launch_gemm(r, C + Kc, batch, s);
+    launch_gemm_staged(r, C + Kc, batch, s);
     A += d;
   }
   // head: a1 = lrelu(W1 lrelu(skip) + b1); logits = W2 a1 + b2   (columns s = 0..S-1)
   Act a1v = act_view(buf->a1, batch, Q, g.Sp);
   {
     DenseOp<IN_LRELU, OUT_BIAS_LRELU, false> h1;
-    h1.K = Kc; h1.t_begin = 0; h1.t_end = g.S; h1.M = Q; h1.wmat = p->head1_w; h1.ldw = Kc;
-    h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v; h1.t_out_end = g.S;
-    launch_gemm(h1, Q, batch, s);
+    h1.K = Kc; h1.t_begin = g.pad; h1.t_end = g.pad + g.S; h1.M = Q; h1.wmat = p->head1_w;
+    h1.ldw = Kc; h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v;
+    h1.t_out_end = g.pad + g.S; h1.aligned_out = 1;
+    launch_gemm_staged(h1, Q, batch, s);
   }
   if (S_out > 0) {
     DenseOp<IN_ID, OUT_BIAS, false> h2;
-    h2.K = Q; h2.t_begin = 0; h2.t_end = g.S; h2.M = Q; h2.wmat = p->head2_w; h2.ldw = Q;
-    h2.bias = p->head2_b; h2.xin = a1v; h2.yout = act_view(out, batch, Q, S_out); h2.ref = a1v;
-    h2.t_out_end = S_out;
-    launch_gemm(h2, Q, batch, s);
+    h2.K = Q; h2.t_begin = g.pad; h2.t_end = g.pad + g.S; h2.M = Q; h2.wmat = p->head2_w; h2.ldw = Q;
+    h2.bias = p->head2_b; h2.xin = a1v; h2.ref = a1v;
+    // `out` is the caller's contiguous (B, Q, S_out): column s of the head = out column s - pad
+    h2.yout = act_view(out - g.pad, batch, Q, S_out);
+    h2.t_out_end = g.pad + S_out; h2.aligned_out = 0;
+    launch_gemm_staged(h2, Q, batch, s);
     if (normalize)
       hipLaunchKernelGGL(softmax_kernel, dim3((S_out + 255) / 256, batch), dim3(256), 0, s, out, Q,
                          S_out);
@@ -651,26 +667,28 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((g.S + 255) / 256, batch), dim3(256), 0, s, out, dout,
-                     dlog, Q, S_out, g.S, normalize);
+                     dlog, Q, S_out, g.S, normalize, g.pad);
   {  // head conv2: weight grad, then data grad (x lrelu'(a1))
     WgDenseOp<IN_ID> w2;
-    w2.t_begin = 0; w2.t_end = g.S; w2.M = Q; w2.N = Q; w2.aact = dlog; w2.xact = a1v;
+    w2.t_begin = g.pad; w2.t_end = g.pad + g.S; w2.M = Q; w2.N = Q; w2.aact = dlog; w2.xact = a1v;
     w2.dwm = gr->head2_w; w2.dbv = gr->head2_b;
     launch_wgrad(w2, Q, Q, batch, bias_scratch, s);
     DenseOp<IN_ID, OUT_MUL_DLRELU, true> d2;
-    d2.K = Q; d2.t_begin = 0; d2.t_end = g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
-    d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.S;
-    launch_gemm(d2, Q, batch, s);
+    d2.K = Q; d2.t_begin = g.pad; d2.t_end = g.pad + g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
+    d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.pad + g.S;
+    d2.aligned_out = 1;
+    launch_gemm_staged(d2, Q, batch, s);
   }
   {  // head conv1
     WgDenseOp<IN_LRELU> w1;
-    w1.t_begin = 0; w1.t_end = g.S; w1.M = Q; w1.N = Kc; w1.aact = da1; w1.xact = skipv;
+    w1.t_begin = g.pad; w1.t_end = g.pad + g.S; w1.M = Q; w1.N = Kc; w1.aact = da1; w1.xact = skipv;
     w1.dwm = gr->head1_w; w1.dbv = gr->head1_b;
     launch_wgrad(w1, Q, Kc, batch, bias_scratch, s);
     DenseOp<IN_ID, OUT_MUL_DLRELU, true> d1;
-    d1.K = Q; d1.t_begin = 0; d1.t_end = g.S; d1.M = Kc; d1.wmat = p->head1_w; d1.ldw = Kc;
-    d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.S;
-    launch_gemm(d1, Kc, batch, s);
+    d1.K = Q; d1.t_begin = g.pad; d1.t_end = g.pad + g.S; d1.M = Kc; d1.wmat = p->head1_w; d1.ldw = Kc;
+    d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.pad + g.S;
+    d1.aligned_out = 1;
+    launch_gemm_staged(d1, Kc, batch, s);
   }
   // layers, last to first
   int A_lo[4096];
@@ -710,33 +728,36 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     Act xin = act_view(fwd->acts + (size_t)l * g.act, batch, C, g.Tp);
     Act dxo = act_view(dxo_p, batch, C, g.Tp);
     WgRsOp wr;
-    wr.t_begin = t_lo; wr.t_end = T; wr.C = C; wr.Kc = Kc; wr.t_skip0 = t_skip0;
+    wr.t_begin = t_lo; wr.t_end = T; wr.C = C; wr.Kc = Kc; wr.t_skip0 = t_skip0; wr.t_base = g.t_base;
     wr.dxo = dxo; wr.dskip = dskip; wr.th = th; wr.sg = sg;
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
     launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s);
     DzOp dz;
     dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
+    dz.t_base = g.t_base;
     dz.wr = p->residual_w[l]; dz.ws = p->skip_w[l];
     dz.dxo = dxo; dz.dskip = dskip; dz.th = th; dz.sg = sg; dz.dfg = dfg;
-    launch_gemm(dz, C, batch, s);
-    WgFgOp wf;
-    wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
-    wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
-    wf.dwcf = has_ctx ? gr->ctx_filter_w[l] : nullptr; wf.dwcg = has_ctx ? gr->ctx_gate_w[l] : nullptr;
-    wf.dbcf = has_ctx ? gr->ctx_filter_b[l] : nullptr; wf.dbcg = has_ctx ? gr->ctx_gate_b[l] : nullptr;
-    launch_wgrad(wf, 2 * C, has_ctx ? 3 * C : 2 * C, batch, has_ctx ? ctx_bias_scratch : nullptr, s);
+    launch_gemm_staged(dz, C, batch, s);
+    auto run_wf = [&](auto wf) {
+      wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
+      wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
+      wf.dwcf = has_ctx ? gr->ctx_filter_w[l] : nullptr; wf.dwcg = has_ctx ? gr->ctx_gate_w[l] : nullptr;
+      wf.dbcf = has_ctx ? gr->ctx_filter_b[l] : nullptr; wf.dbcg = has_ctx ? gr->ctx_gate_b[l] : nullptr;
+      launch_wgrad(wf, 2 * C, has_ctx ? 3 * C : 2 * C, batch, has_ctx ? ctx_bias_scratch : nullptr, s);
+    };
+    if (has_ctx) run_wf(WgFgOpT<true>()); else run_wf(WgFgOpT<false>());
     if (has_ctx) {
       DctxOp dc;
       dc.K = 2 * C; dc.t_begin = t_lo; dc.t_end = T; dc.C = C;
       dc.wcf = p->ctx_filter_w[l]; dc.wcg = p->ctx_gate_w[l]; dc.dfg = dfg; dc.dctx = dctxv;
-      launch_gemm(dc, C, batch, s);
+      launch_gemm_staged(dc, C, batch, s);
     }
     DxOp dx;
     dx.K = 4 * C; dx.t_begin = A_lo[l]; dx.t_end = T; dx.C = C; dx.d = d; dx.t_lo = t_lo;
     dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];
     dx.dxo = dxo; dx.dfg = dfg; dx.dxi = act_view(cur, batch, C, g.Tp);
-    launch_gemm(dx, C, batch, s);
+    launch_gemm_staged(dx, C, batch, s);
     dxo_p = cur;
     float *tmp = cur; cur = nxt; nxt = tmp;
   }

@@ -49,7 +49,7 @@ class ForwardBuffers:
         L = dims.layer_size * dims.stack_size
         C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
         S = N.check(lib.mvn_output_size(dims, t_len), "mvn_output_size")
-        self.S, self.Tp, self.Sp = S, lib.mvn_padded_len(t_len), lib.mvn_padded_len(S)
+        self.S, self.Tp, self.Sp = S, lib.mvn_padded_len(t_len), lib.mvn_padded_len(S + 3)
         f32 = dict(dtype=torch.float32, device=device)
         self.acts = torch.empty(((L + 1) if save else 2, batch, C, self.Tp), **f32)
         self.th = torch.empty((L, batch, C, self.Tp), **f32) if save else None
