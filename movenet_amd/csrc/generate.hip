@@ -36,8 +36,18 @@ __device__ __forceinline__ void matvec_parts(const float *__restrict__ Wt, const
   for (int w = threadIdx.x; w < P * nout; w += blockDim.x) {
     const int p = w / nout, o = w - p * nout;
     const int k0 = p * chunk, k1 = min(nin, k0 + chunk);
+    // 8 independent weight loads in flight per thread (this loop is L2-latency bound),
+    // summed in the original k order
     float acc = 0.f;
-    for (int k = k0; k < k1; ++k) acc = fmaf(Wt[(size_t)k * nout + o], x[k], acc);
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float wv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[i] = Wt[(size_t)(k + i) * nout + o];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(wv[i], x[k + i], acc);
+    }
+    for (; k < k1; ++k) acc = fmaf(Wt[(size_t)k * nout + o], x[k], acc);
     part[w] = acc;
   }
 }
@@ -75,7 +85,7 @@ __device__ float block_sum_g(float v, float *red) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void gen_generic_kernel(GenArgs a) {
+__global__ __launch_bounds__(1024) void gen_generic_kernel(GenArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x, b = blockIdx.x;
   const int C = a.C, K = a.K, Q = a.Q, L = a.L;
@@ -621,10 +631,15 @@ __global__ void pack_head_s64_kernel(const float *w1, const float *b1, const flo
   }
 }
 
+// wide models keep more weight loads in flight with a 1024-thread workgroup
+static int generic_threads(const mvn_dims *d) {
+  return (2 * d->residual_channels >= 256 || d->input_channels >= 512) ? 1024 : 256;
+}
+
 static size_t generic_lds_bytes(const mvn_dims *d) {
   const int C = d->residual_channels, K = d->skip_channels, Q = d->input_channels;
   const int L = n_layers(d);
-  int partsz = 256;
+  int partsz = generic_threads(d);
   if (2 * C > partsz) partsz = 2 * C;
   if (C + K > partsz) partsz = C + K;
   if (Q > partsz) partsz = Q;
@@ -889,7 +904,8 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
       if (rc) return rc;
       attr_set = true;
     }
-    hipLaunchKernelGGL(mvn::gen_generic_kernel, dim3(batch), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mvn::gen_generic_kernel, dim3(batch), dim3(mvn::generic_threads(dims)), lds,
+                       (hipStream_t)stream, a);
   }
   return mvn::check_hip(hipGetLastError(), "mvn_generate");
 }

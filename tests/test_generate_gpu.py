@@ -167,3 +167,23 @@ def test_bad_input_raises():
         model.generate(bad, n_samples=30, temperature=0.0)
     with pytest.raises(RuntimeError):
         model.generate(torch.zeros(1, 64, 20), n_samples=30)
+
+
+def test_config5_shape_generate_vs_oracle():
+    """BASELINE config 5's model (60 layers, C=K=128, RF=6144) through the GENERIC fp32
+    kernel: greedy free run == the CPU ring oracle, logits within tolerance of it.
+    (A tuned fp16-operand kernel for this shape is future work: DESIGN.md section 7.)"""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
+    sd = make_state_dict(**cfg, seed=2, gain=1.5, head_gain=6.0)
+    dims = O.Dims(**cfg)
+    rf, n_new, B = dims.receptive_fields, 12, 1
+    pidx = synthetic_indices(B, rf, 256, 5)
+    want, want_logits = O.generate_ring(sd, dims, pidx.numpy(), rf + n_new)
+    g = _gen(cfg, sd, B, rf + n_new)
+    g.prime(pidx.to(DEV))
+    g.advance(n_new)
+    g.check_errors()
+    assert np.array_equal(g.samples.cpu().numpy(), want)
+    _, logits = g.teacher_forced(torch.from_numpy(want).to(DEV), logits_t0=rf)
+    assert rel_err(logits.cpu().numpy(), want_logits) < LOGIT_TOL
