@@ -289,7 +289,7 @@ def main():
                 "batch_per_gpu": BATCH,
                 "new_samples_per_sequence_per_step": n_new,
                 "prompt": rf,
-                "kernel_variant": {1: "generic", 2: "stream64", 3: "pipe64"}[variant_used],
+                "kernel_variant": {1: "generic", 2: "stream64", 3: "pipe"}[variant_used],
                 "parallelism": f"independent clips x{world} (no collective)",
             },
             "samples_per_s_per_gpu": value / world,
@@ -308,7 +308,7 @@ def main():
                 # sequences: profiles/r01_pmc_gen_pipe64_fetch_write.csv), scaled to this launch
                 "traffic": (PMC_BYTES_PER_STEP_SEQ * BATCH * n_new) if variant_used == 3 else None,
                 "traffic_unit": "bytes per launch (HBM side; the 12.6 MB of dilation queues stay in L2/MALL)",
-                "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe64_kernel"}[variant_used],
+                "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>"}[variant_used],
                 "flop_per_launch": flops_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,
                 "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",

@@ -96,9 +96,10 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
 #define MVN_GEN_AUTO 0
 #define MVN_GEN_GENERIC 1
 #define MVN_GEN_STREAM 2
-#define MVN_GEN_PIPE 3 /* C=K=64, Q=256: layer pipeline over ceil(L/4)+1 CUs per
-                          sequence, weights resident in registers/LDS, activations
-                          handed on as sc1 granules; needs batch*stages <= #CUs   */
+#define MVN_GEN_PIPE 3 /* C=K in {64,128}, Q=256: layer pipeline over ceil(L/4)+1 (C=64)
+                          or L+1 (C=128) CUs per sequence, weights resident in
+                          registers/LDS, activations handed on as 8-byte granules;
+                          needs all stages co-resident, at most 32 per XCD         */
 
 /* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
  * variant or a negative error.  The packed weight layout depends on the variant:
@@ -109,6 +110,11 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch);
  * queues, plus the PIPE variant's hand-off area when the dims allow PIPE). */
 size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant);
 size_t mvn_gen_state_floats(const mvn_dims *dims, int batch);
+
+/* Float offset, inside the state, of the PIPE variant's status word (int32, zero =
+ * no hand-off timed out since the state was last zeroed; read it after synchronising
+ * the stream); (size_t)-1 when the dims have no PIPE hand-off area. */
+size_t mvn_gen_status_offset(const mvn_dims *dims, int batch);
 
 /* state_dict layouts -> the variant's streaming layout (done once per weight
  * update; DESIGN.md "Data layout in HBM"). */

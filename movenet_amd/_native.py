@@ -97,6 +97,7 @@ SIGNATURES = {
     "mvn_gen_variant": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_int]),
     "mvn_gen_weights_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_state_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
+    "mvn_gen_status_offset": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_pack_weights": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(Params), C.c_void_p,
                                        C.c_void_p]),
     "mvn_generate": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -650,8 +650,8 @@ static size_t generic_lds_bytes(const mvn_dims *d) {
 static size_t gen_base_floats(const mvn_dims *dims, int variant) {
   const size_t C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const size_t L = n_layers(dims);
-  if (variant == MVN_GEN_STREAM || variant == MVN_GEN_PIPE)
-    return s64::EMB_FLOATS + 4 * (L * s64::LAYER_F4 + s64::HEAD_F4);
+  if (variant == MVN_GEN_PIPE) return pipe_weights_floats(dims);
+  if (variant == MVN_GEN_STREAM) return s64::EMB_FLOATS + 4 * (L * s64::LAYER_F4 + s64::HEAD_F4);
   return 2 * Q * C + L * (4 * C * C + C * (C + K) + (C + K)) + K * Q + Q + Q * Q + Q;
 }
 
@@ -722,14 +722,16 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   int rc = mvn::validate_dims(dims);
   if (rc) return rc;
   const bool pipe_fits =
-      mvn::pipe_ok(dims) && batch >= 1 && batch * mvn::pipe_stages(dims) <= device_cus();
+      mvn::pipe_ok(dims) && batch >= 1 && device_cus() >= 256 && batch <= mvn::pipe_max_batch(dims);
   if (requested == MVN_GEN_AUTO) {
     if (pipe_fits) return MVN_GEN_PIPE;
     return mvn::stream_ok(dims) ? MVN_GEN_STREAM : MVN_GEN_GENERIC;
   }
   if (requested == MVN_GEN_PIPE) {
     if (!pipe_fits) {
-      mvn::set_error("PIPE variant needs C=K=64, Q=256 and batch*(ceil(L/4)+1) <= number of CUs");
+      mvn::set_error("PIPE variant needs C=K in {64,128}, Q=256, 256 CUs and batch <= %d for these "
+                     "dims (stages per sequence: ceil(L/4)+1 at C=64, L+1 at C=128; 32 per XCD)",
+                     mvn::pipe_ok(dims) ? mvn::pipe_max_batch(dims) : 0);
       return MVN_ERR_UNSUPPORTED;
     }
     return MVN_GEN_PIPE;
@@ -763,10 +765,17 @@ size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant) {
 
 size_t mvn_gen_state_floats(const mvn_dims *dims, int batch) {
   if (mvn::validate_dims(dims) || batch < 0) return 0;
-  // dilation queues, then (C=K=64, Q=256 only) the PIPE variant's hand-off area
+  // dilation queues, then (C=K in {64,128}, Q=256 only) the PIPE variant's hand-off area
   size_t n = (size_t)batch * (size_t)mvn::dilation_sum(dims) * dims->residual_channels;
   if (mvn::pipe_ok(dims)) n += mvn::pipe_hand_floats(dims, batch);
   return n;
+}
+
+size_t mvn_gen_status_offset(const mvn_dims *dims, int batch) {
+  if (mvn::validate_dims(dims) || batch < 0 || !mvn::pipe_ok(dims)) return (size_t)-1;
+  // queues | batch * stages inboxes of 2C granules (2 floats each) | status word ...
+  return (size_t)batch * (size_t)mvn::dilation_sum(dims) * dims->residual_channels +
+         (size_t)batch * mvn::pipe_stages(dims) * 4 * dims->residual_channels;
 }
 
 int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p, float *packed,

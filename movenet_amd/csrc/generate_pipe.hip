@@ -28,18 +28,32 @@ namespace mvn {
 typedef unsigned long long u64;
 typedef float4 f4;
 
-namespace p64 {
-constexpr int C = 64, Q = 256, NT = 512, LPS = 4;
-constexpr int MAT_F = 8192;                  // one 128x64 matrix
-constexpr int LAYER_F = 3 * MAT_F + 128;     // WC | WP | WR | brs
-constexpr int EMB_F = 2 * Q * C;
-constexpr int W1_F = Q * C, W2_F = Q * Q;
-constexpr int HEAD_F = W1_F + Q + W2_F + Q;
-constexpr int CTX_LAYER_F = MAT_F + 128;     // context section per layer: Wcf|Wcg rows + biases
-constexpr int GRAN = 128;                    // granules per inbox
-constexpr int LDS_FLOATS = 33408;            // max(layer stage, head stage) + 16 flag words
-constexpr unsigned SPIN_LIMIT = 1u << 23;
-}  // namespace p64
+// Shape traits.  C = K = 64: 4 layers per stage, a thread owns 2 rows x 16 inputs (4 lanes
+// per channel).  C = K = 128 (BASELINE config 5): the 3 x 128 KB of a single layer already
+// fill a CU, so 1 layer per stage, 2 rows x 64 inputs per thread (2 lanes per channel).
+constexpr int PIPE_XCD_CUS = 32;  // CUs per XCD: one workgroup (133 KB of LDS) per CU
+template <int CC>
+struct PipeCfg {
+  static constexpr int C = CC, Q = 256, NT = 512;
+  static constexpr int LPS = CC == 64 ? 4 : 1;    // layers per stage
+  static constexpr int KQ = 256 / CC;             // lanes sharing one channel's two rows
+  static constexpr int KPER = CC / KQ;            // inputs per lane
+  static constexpr int NF4 = KPER / 4;            // float4 per row per lane
+  static constexpr int MAT_F = 2 * CC * CC;       // one 2C x C matrix
+  static constexpr int LAYER_F = 3 * MAT_F + 2 * CC;   // WC | WP | WR | biases
+  static constexpr int CTX_LAYER_F = MAT_F + 2 * CC;   // context section per layer
+  static constexpr int EMB_F = 2 * Q * CC;
+  static constexpr int W1_F = Q * CC, W2_F = Q * Q;
+  static constexpr int HEAD_F = W1_F + Q + W2_F + Q;
+  static constexpr int GRAN = 2 * CC;             // granules per inbox: residual | skip sum
+  static constexpr int GL = GRAN / 64;            // granules per polling lane
+  static constexpr int W1N = CC / 2;              // head conv1 inputs per thread (2 threads per row)
+  // LDS floats: layer stage LPS*MAT_F + (4 + LPS)*C; head stage: tables or conv1 weights
+  // (32768 either way) + a0[C] + a1[Q] + logits[Q]; + 16 flag words
+  static constexpr int LDS_FLOATS = 32768 + 8 * CC + 2 * Q + 64 + 16;
+};
+constexpr unsigned PIPE_SPIN_LIMIT = 1u << 23;
+constexpr int PIPE_MAX_GRAN = 256;
 
 #ifdef MVN_PIPE_STAMPS
 // Diagnostic build only (python -m movenet_amd.csrc.build --stamps): wall-clock
@@ -78,23 +92,40 @@ __device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v, boo
     __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Wave 0 only.  Lane i owns granules 2i and 2i+1 of the inbox.  Returns false on
-// time-out / raised error word (wave-uniform).
-__device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsigned *err, float &v0,
-                                           float &v1) {
+// Wave 0 only.  One 16-byte load fetches two granules, and the 64 lanes of a load cover
+// 1 KB of the inbox contiguously: lane i owns granules 128*k + 2*i and 128*k + 2*i + 1 for
+// k < GL/2 (v[2k], v[2k+1]).  Each granule is still validated by its own epoch word; a
+// 16-byte aligned load never tears an 8-byte store.  Returns false on time-out / raised
+// error word (wave-uniform).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <int GL>
+__device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsigned *err,
+                                           float (&v)[GL]) {
+  static_assert(GL == 2 || GL == 4, "one or two 16-byte loads per lane");
   const int lane = threadIdx.x & 63;
+  const u64 *p = in + 2 * lane;
   for (unsigned spins = 1;; ++spins) {
-    const u64 g0 = __hip_atomic_load(in + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 g1 = __hip_atomic_load(in + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool ok = (unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch;
+    v4u g0, g1 = {0u, epoch, 0u, epoch};
+    if (GL == 2)
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(g0) : "v"(p) : "memory");
+    else
+      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                   "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(g0), "=&v"(g1) : "v"(p) : "memory");
+    const bool ok = g0.y == epoch && g0.w == epoch && g1.y == epoch && g1.w == epoch;
     if (__all(ok)) {
-      v0 = __uint_as_float((unsigned)g0);
-      v1 = __uint_as_float((unsigned)g1);
+      v[0] = __uint_as_float(g0.x);
+      v[1] = __uint_as_float(g0.z);
+      if (GL == 4) {
+        v[GL - 2] = __uint_as_float(g1.x);
+        v[GL - 1] = __uint_as_float(g1.z);
+      }
       return true;
     }
     if ((spins & 255u) == 0) {
       const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins > p64::SPIN_LIMIT) {
+      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
         if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
@@ -156,53 +187,110 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define MVN_EXP 0   // timing experiments of scripts/pipe_stamps.py; 0 = the product
 #endif
 
-// 16-term dot product as 8 packed FMAs (v_pk_fma_f32) in two independent chains,
-// combined in a fixed order.  w: 8 float2, x: 16 consecutive floats in LDS (already
-// fetched as four float4 by the caller).
-__device__ __forceinline__ float dot16(const v2f (&w)[8], const f4 (&x)[4]) {
-  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a0 = __builtin_elementwise_fma(w[2 * i], v2f{x[i].x, x[i].y}, a0);
-    a1 = __builtin_elementwise_fma(w[2 * i + 1], v2f{x[i].z, x[i].w}, a1);
-  }
-  const v2f t = a0 + a1;
-  return t.x + t.y;
-}
-// 32-term dot product as 16 packed FMAs in four chains (head)
-__device__ __forceinline__ float dot32(const v2f (&w)[16], const float *x) {
-  const f4 *x4 = (const f4 *)x;
+// N4*4-term dot product as packed FMAs (v_pk_fma_f32) in two (N4 = 4) or four independent
+// chains, combined in a fixed order.  w: 2*N4 float2, x: the inputs already fetched from LDS.
+template <int N4>
+__device__ __forceinline__ float dotn(const v2f (&w)[2 * N4], const f4 (&x)[N4]) {
   v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    const f4 xv = x4[i], yv = x4[i + 1];
-    a0 = __builtin_elementwise_fma(w[2 * i], v2f{xv.x, xv.y}, a0);
-    a1 = __builtin_elementwise_fma(w[2 * i + 1], v2f{xv.z, xv.w}, a1);
-    a2 = __builtin_elementwise_fma(w[2 * i + 2], v2f{yv.x, yv.y}, a2);
-    a3 = __builtin_elementwise_fma(w[2 * i + 3], v2f{yv.z, yv.w}, a3);
+  for (int i = 0; i < N4; i += 2) {
+    a0 = __builtin_elementwise_fma(w[2 * i], v2f{x[i].x, x[i].y}, a0);
+    a1 = __builtin_elementwise_fma(w[2 * i + 1], v2f{x[i].z, x[i].w}, a1);
+    a2 = __builtin_elementwise_fma(w[2 * i + 2], v2f{x[i + 1].x, x[i + 1].y}, a2);
+    a3 = __builtin_elementwise_fma(w[2 * i + 3], v2f{x[i + 1].z, x[i + 1].w}, a3);
   }
-  const v2f t = (a0 + a1) + (a2 + a3);
+  const v2f t = (a0 + a2) + (a1 + a3);
   return t.x + t.y;
 }
-__device__ __forceinline__ void load32(v2f (&w)[16], const f4 *src, int stride, int idx) {
+template <int N4>
+__device__ __forceinline__ void ldsn(f4 (&x)[N4], const float *p) {
+#if MVN_EXP == 2  // experiment: 1/N4 of the LDS traffic
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N4; ++i) x[i] = ((const f4 *)p)[0];
+#else
+#pragma unroll
+  for (int i = 0; i < N4; ++i) x[i] = ((const f4 *)p)[i];
+#endif
+}
+// N4 float4 of a [..][stride] block -> 2*N4 float2 registers
+template <int N4>
+__device__ __forceinline__ void loadn(v2f (&w)[2 * N4], const f4 *src, int stride, int idx) {
+#pragma unroll
+  for (int i = 0; i < N4; ++i) {
     const f4 v = src[i * stride + idx];
     w[2 * i] = v2f{v.x, v.y};
     w[2 * i + 1] = v2f{v.z, v.w};
   }
 }
-// two rows x 16 inputs: wa <- float4 0..3, wb <- float4 4..7 of a [8][stride] block
-__device__ __forceinline__ void load2x16(v2f (&wa)[8], v2f (&wb)[8], const f4 *src, int stride,
-                                         int idx) {
+// Two rows against the same LDS vector, the vector fetched four float4 at a time with one
+// chunk of look-ahead: at N4 = 16 only 32-48 of its 64 registers are live at once (the
+// whole vector next to 128 weight registers spills).  Same accumulation order as dotn.
+template <int N4>
+__device__ __forceinline__ void dot2_lds(const v2f (&wa)[2 * N4], const v2f (&wb)[2 * N4],
+                                         const float *xp, float &ra, float &rb) {
+  constexpr int CH = 4, NCH = N4 / CH;
+  static_assert(N4 % CH == 0, "whole chunks");
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+  v2f b0 = {0.f, 0.f}, b1 = {0.f, 0.f}, b2 = {0.f, 0.f}, b3 = {0.f, 0.f};
+  f4 x[N4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f4 u = src[i * stride + idx], v = src[(4 + i) * stride + idx];
-    wa[2 * i] = v2f{u.x, u.y};
-    wa[2 * i + 1] = v2f{u.z, u.w};
-    wb[2 * i] = v2f{v.x, v.y};
-    wb[2 * i + 1] = v2f{v.z, v.w};
+  for (int i = 0; i < CH; ++i) x[i] = ((const f4 *)xp)[i];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) {
+#pragma unroll
+      for (int i = CH * (ch + 1); i < CH * (ch + 2); ++i) x[i] = ((const f4 *)xp)[i];
+    }
+    if (NCH > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = CH * ch; i < CH * (ch + 1); i += 2) {
+      const v2f x0 = {x[i].x, x[i].y}, x1 = {x[i].z, x[i].w};
+      const v2f x2 = {x[i + 1].x, x[i + 1].y}, x3 = {x[i + 1].z, x[i + 1].w};
+      a0 = __builtin_elementwise_fma(wa[2 * i], x0, a0);
+      a1 = __builtin_elementwise_fma(wa[2 * i + 1], x1, a1);
+      a2 = __builtin_elementwise_fma(wa[2 * i + 2], x2, a2);
+      a3 = __builtin_elementwise_fma(wa[2 * i + 3], x3, a3);
+      b0 = __builtin_elementwise_fma(wb[2 * i], x0, b0);
+      b1 = __builtin_elementwise_fma(wb[2 * i + 1], x1, b1);
+      b2 = __builtin_elementwise_fma(wb[2 * i + 2], x2, b2);
+      b3 = __builtin_elementwise_fma(wb[2 * i + 3], x3, b3);
+    }
+    if (NCH > 1) __builtin_amdgcn_sched_barrier(0);
   }
+  const v2f ta = (a0 + a2) + (a1 + a3), tb = (b0 + b2) + (b1 + b3);
+  ra = ta.x + ta.y;
+  rb = tb.x + tb.y;
+}
+// dotn() with the weights fetched on the fly (LDS or L2), four float4 at a time so that
+// only 32 registers are live; same accumulators and order as dotn: bit-identical to it
+template <int N4>
+__device__ __forceinline__ float dot_stream(const f4 *wsrc, int stride, int idx, const float *xsrc) {
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll
+  for (int i0 = 0; i0 < N4; i0 += 4) {
+    f4 w[4], x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = wsrc[(i0 + i) * stride + idx];
+      x[i] = ((const f4 *)xsrc)[i0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      a0 = __builtin_elementwise_fma(v2f{w[i].x, w[i].y}, v2f{x[i].x, x[i].y}, a0);
+      a1 = __builtin_elementwise_fma(v2f{w[i].z, w[i].w}, v2f{x[i].z, x[i].w}, a1);
+      a2 = __builtin_elementwise_fma(v2f{w[i + 1].x, w[i + 1].y}, v2f{x[i + 1].x, x[i + 1].y}, a2);
+      a3 = __builtin_elementwise_fma(v2f{w[i + 1].z, w[i + 1].w}, v2f{x[i + 1].z, x[i + 1].w}, a3);
+    }
+  }
+  const v2f t = (a0 + a2) + (a1 + a3);
+  return t.x + t.y;
+}
+// sum over the KQ lanes that share a channel (result in all of them)
+template <int KQ>
+__device__ __forceinline__ float chan_sum(float v) {
+  v += dpp_mov<DPP_XOR1>(v);
+  if (KQ == 4) v += dpp_mov<DPP_XOR2>(v);
+  return v;
 }
 
 // (value, index) arg-max combine: larger value wins, smaller index on ties
@@ -220,24 +308,37 @@ __device__ __forceinline__ int dpp_movi(int v) {
 // Workgroup = 8 waves.  Waves 0-3 ("FG group") own the filter/gate matrices, waves
 // 4-7 ("RS group") the residual/skip matrices: at any moment ONE wave per SIMD is
 // issuing, so the dependent chain is not slowed by a co-resident wave replaying the
-// same bookkeeping instructions, and each thread keeps 4 layers x 32 weights = 128
+// same bookkeeping instructions, and each thread keeps LPS x 2 x KPER weights = 128
 // VGPRs resident.
-__global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand, unsigned *err,
-                                                           int NS, int nb) {
-  using namespace p64;
+template <int CC>
+__global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, unsigned *err, int NS,
+                                                         int nb) {
+  using P = PipeCfg<CC>;
+  constexpr int C = P::C, Q = P::Q, NT = P::NT, LPS = P::LPS, KQ = P::KQ, KPER = P::KPER;
+  constexpr int NF4 = P::NF4, MAT_F = P::MAT_F, GRAN = P::GRAN, GL = P::GL;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // Workgroups i and i+8 are observed to land on the same XCD: lay the NS stages of a
-  // pipeline out with stride 8 so that its hops stay inside one L2 (speed only; every
-  // edge verifies its placement below).
-  const int slot = blockIdx.x >> 3;
-  const int b = (blockIdx.x & 7) + 8 * (slot / NS), s = slot - (slot / NS) * NS;
+  // Workgroup i is dispatched to XCD i % 8 (observed; every edge verifies its placement
+  // below, so this is speed only -- but co-residency needs <= 32 workgroups per XCD, which
+  // the host checks with the same arithmetic).  A pipeline of NS <= 32 stages sits in
+  // one XCD so that its hops stay inside one L2; a longer one spans XS adjacent XCDs.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int b, s;
+  if (NS <= PIPE_XCD_CUS) {
+    b = xcd + 8 * (slot / NS);
+    s = slot % NS;
+  } else {
+    const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS, SPX = (NS + XS - 1) / XS;
+    b = xcd / XS;
+    s = (xcd % XS) * SPX + slot;
+    if (slot >= SPX || s >= NS) return;
+  }
   if (b >= nb) return;
   const int L = a.L;
   const int s_next = s + 1 == NS ? 0 : s + 1;
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
   u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
-  int *iflag = (int *)(smem + LDS_FLOATS - 16);  // [0] ok flag, [1] idx_cur, [2] idx_prev
+  int *iflag = (int *)(smem + P::LDS_FLOATS - 16);  // [0] ok flag, [3] fast-edge flag
   // placement handshake: publish my XCC id (+1), read my consumer's
   bool fast_edge = false;
   {
@@ -259,22 +360,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
 
   if (s < NS - 1) {
     // ================= layer stage: layers l0 .. l0+nl-1 =================
-    // FG group thread t: channel c = t>>2, rows f_c and g_c, inputs k in [16kq, 16kq+16);
-    // RS group thread t: channel c = t>>2, rows res_c and skip_c, same k split.  A row is
-    // finished by a 4-lane DPP sum; each lane fetches 16 inputs (4 x ds_read_b128).
+    // FG group thread t: channel c = t / KQ, rows f_c and g_c, inputs k in [KPER*kq, +KPER);
+    // RS group thread t: channel c, rows res_c and skip_c, same k split.  A row is finished
+    // by a KQ-lane DPP sum; each lane fetches KPER inputs (NF4 x ds_read_b128).
     const int l0 = s * LPS, nl = min(LPS, L - l0);
     const bool fg_group = tid < 256;
-    const int t = tid & 255, c = t >> 2, kq = t & 3;
+    const int t = tid & 255, c = t / KQ, kq = t % KQ;
     const bool lead = kq == 0;
-    float *wp = smem;                  // [LPS][8][256] float4: past-tap f|g weights (FG group)
-    float *cur = smem + LPS * MAT_F;   // [64] residual stream
-    float *zb = cur + 64;              // [64] gated activation
-    float *pastb = zb + 64;            // [LPS][64] popped queue entries
-    float *skin = pastb + LPS * 64;    // [64] running skip sum as received
-    float *ctxb = skin + 64;           // [64] context vector of the step being prepared
+    float *wp = smem;                  // [LPS][2*NF4][256] float4: past-tap f|g weights (FG group)
+    float *cur = smem + LPS * MAT_F;   // [C] residual stream
+    float *zb = cur + C;               // [C] gated activation
+    float *pastb = zb + C;             // [LPS][C] popped queue entries
+    float *skin = pastb + LPS * C;     // [C] running skip sum as received
+    float *ctxb = skin + C;            // [C] context vector of the step being prepared
     float *ring = a.state + (size_t)b * a.state_per_seq;
 
-    v2f wa[LPS][8], wb[LPS][8];        // FG: f_c | g_c current-tap rows; RS: res_c | skip_c rows
+    v2f wa[LPS][2 * NF4], wb[LPS][2 * NF4];  // FG: f_c | g_c current-tap rows; RS: res_c | skip_c
     float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
     int doff[LPS], dmask[LPS];
 #pragma unroll
@@ -282,18 +383,21 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       bias_r[j] = 0.f; bias_s[j] = 0.f; pf[j] = 0.f; pg[j] = 0.f; xs[j] = 0.f;
       doff[j] = 0; dmask[j] = 0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { wa[j][i] = v2f{0.f, 0.f}; wb[j][i] = v2f{0.f, 0.f}; }
+      for (int i = 0; i < 2 * NF4; ++i) { wa[j][i] = v2f{0.f, 0.f}; wb[j][i] = v2f{0.f, 0.f}; }
       if (j < nl) {
-        const float *lw = a.w + EMB_F + (size_t)(l0 + j) * LAYER_F;
+        const float *lw = a.w + P::EMB_F + (size_t)(l0 + j) * P::LAYER_F;
         if (fg_group) {
-          load2x16(wa[j], wb[j], (const f4 *)lw, 256, t);
+          loadn<NF4>(wa[j], (const f4 *)lw, 256, t);
+          loadn<NF4>(wb[j], (const f4 *)lw + NF4 * 256, 256, t);
           const f4 *wp4 = (const f4 *)(lw + MAT_F);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ((f4 *)wp)[(j * 8 + i) * 256 + t] = wp4[i * 256 + t];
+          for (int i = 0; i < 2 * NF4; ++i)
+            ((f4 *)wp)[(j * 2 * NF4 + i) * 256 + t] = wp4[i * 256 + t];
         } else {
-          load2x16(wa[j], wb[j], (const f4 *)(lw + 2 * MAT_F), 256, t);
+          loadn<NF4>(wa[j], (const f4 *)(lw + 2 * MAT_F), 256, t);
+          loadn<NF4>(wb[j], (const f4 *)(lw + 2 * MAT_F) + NF4 * 256, 256, t);
           bias_r[j] = lw[3 * MAT_F + c];
-          bias_s[j] = lw[3 * MAT_F + 64 + c];
+          bias_s[j] = lw[3 * MAT_F + C + c];
         }
         const int l = l0 + j;
         dmask[j] = (1 << (l % a.layer_size)) - 1;
@@ -305,38 +409,40 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     // pop the entries step tn needs (RS lead lanes), then the past-tap half of step
     // tn's f/g pre-activations (FG group).
     auto precompute = [&](int tn, bool push) {
+      // `tq` is the thread index behind an optimisation fence: every address below is
+      // recomputed here instead of being kept in registers across the step loop (the
+      // critical path needs those registers; this code has slack)
+      int tq = t;
+      asm volatile("" : "+v"(tq));
+      const int cq = tq / KQ, kk = tq % KQ;
       if (!fg_group && lead) {
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
           if (j < nl) {
-            float *base = ring + doff[j] + c;
+            float *base = ring + doff[j] + cq;
             if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
             const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
-            pastb[j * 64 + c] = pv;
+            pastb[j * C + cq] = pv;
           }
       }
-      if (a.ctx_tm && fg_group && t < 64)
-        ctxb[t] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + t];
+      if (a.ctx_tm && fg_group && tq < C)
+        ctxb[tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
       if (fg_group) {
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
           if (j < nl) {
-            v2f qa[8], qb[8];
-            load2x16(qa, qb, (const f4 *)wp + j * 8 * 256, 256, t);
-            const f4 *x4 = (const f4 *)(pastb + j * 64 + 16 * kq);
-            const f4 x[4] = {x4[0], x4[1], x4[2], x4[3]};
-            pf[j] = quad_sum(dot16(qa, x));
-            pg[j] = quad_sum(dot16(qb, x));
+            const f4 *wpj = (const f4 *)wp + j * 2 * NF4 * 256;
+            pf[j] = chan_sum<KQ>(dot_stream<NF4>(wpj, 256, tq, pastb + j * C + KPER * kk));
+            pg[j] = chan_sum<KQ>(dot_stream<NF4>(wpj + NF4 * 256, 256, tq, pastb + j * C + KPER * kk));
             if (a.ctx_tm) {
               // 1x1 context convs (modules.py:58-63, :75-77): their weights are streamed
-              // from L2 here, off the critical path (32 KB per layer per step)
-              const float *wc = a.wctx + (size_t)(l0 + j) * CTX_LAYER_F;
-              load2x16(qa, qb, (const f4 *)wc, 256, t);
-              const f4 *c4 = (const f4 *)(ctxb + 16 * kq);
-              const f4 cx[4] = {c4[0], c4[1], c4[2], c4[3]};
-              pf[j] += quad_sum(dot16(qa, cx)) + wc[MAT_F + c];
-              pg[j] += quad_sum(dot16(qb, cx)) + wc[MAT_F + 64 + c];
+              // from L2 here, off the critical path
+              const float *wc = a.wctx + (size_t)(l0 + j) * P::CTX_LAYER_F;
+              pf[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc, 256, tq, ctxb + KPER * kk)) +
+                       wc[MAT_F + cq];
+              pg[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc + NF4 * 256, 256, tq, ctxb + KPER * kk)) +
+                       wc[MAT_F + C + cq];
             }
           }
       }
@@ -347,13 +453,20 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     for (int ts = a.t_begin; ts < a.t_end; ++ts) {
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       if (wave == 0) {
-        float v0, v1;
-        const bool ok = wait_inbox(inbox, epoch, err, v0, v1);
+        float v[GL];
+        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
         if (ok) {
-          // granules 0..63 residual stream, 64..127 running skip sum
-          float *dst = lane < 32 ? cur : skin - 64;
-          dst[2 * lane] = v0;
-          dst[2 * lane + 1] = v1;
+          // granules 0..C-1 residual stream, C..2C-1 running skip sum
+          if (GL == 2) {
+            float *dst = lane < 32 ? cur + 2 * lane : skin + 2 * (lane - 32);
+            dst[0] = v[0];
+            dst[1] = v[1];
+          } else {
+            cur[2 * lane] = v[0];
+            cur[2 * lane + 1] = v[1];
+            skin[2 * lane] = v[GL - 2];
+            skin[2 * lane + 1] = v[GL - 1];
+          }
         }
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
@@ -364,26 +477,30 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       for (int j = 0; j < LPS; ++j)
         if (j < nl) {
           float old = 0.f;
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 0, 0);
           if (fg_group) {
-            const f4 *x4 = (const f4 *)(cur + 16 * kq);
-            const f4 x[4] = {x4[0], x4[1], x4[2], x4[3]};
-            const float f = quad_sum(dot16(wa[j], x)) + pf[j];
-            const float g = quad_sum(dot16(wb[j], x)) + pg[j];
+            float f, g;
+            dot2_lds<NF4>(wa[j], wb[j], cur + KPER * kq, f, g);
+            f = chan_sum<KQ>(f) + pf[j];
+            g = chan_sum<KQ>(g) + pg[j];
 #if MVN_EXP == 1
             const float z = f + g;
 #else
             const float z = gate_fast(f, g);
 #endif
             if (lead) zb[c] = z;
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 1, 0);
           } else if (lead) {
             old = cur[c];  // this layer's input: residual add below, queue push later
           }
           lds_barrier();
           if (!fg_group) {
-            const f4 *z4 = (const f4 *)(zb + 16 * kq);
-            const f4 x[4] = {z4[0], z4[1], z4[2], z4[3]};
-            const float r = quad_sum(dot16(wa[j], x));
-            const float k = quad_sum(dot16(wb[j], x));
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 256);
+            float r, k;
+            dot2_lds<NF4>(wa[j], wb[j], zb + KPER * kq, r, k);
+            r = chan_sum<KQ>(r);
+            k = chan_sum<KQ>(k);
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 256);
             if (lead) {
               xs[j] = old;
               const float outv = (r + bias_r[j]) + old;
@@ -392,11 +509,13 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
               if (j == nl - 1) {
                 // the stage's last layer: hand the activation on before anything else
                 put_granule(outbox + c, epoch, outv, fast_edge);
-                put_granule(outbox + 64 + c, epoch, skipacc, fast_edge);
+                put_granule(outbox + C + c, epoch, skipacc, fast_edge);
               }
             }
+            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 4, 256);
           }
           lds_barrier();
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 5, 0);
         }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
       if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
@@ -414,27 +533,36 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
 
   // ============================ head stage ============================
   {
-    float *E0 = smem, *E1 = smem + Q * C;   // [Q][C] each
-    float *a0 = smem + EMB_F;                // [64]
-    float *a1 = a0 + 64;                     // [256]
-    float *lgb = a1 + 256;                   // [256] logits
-    const float *hw = a.w + EMB_F + (size_t)L * LAYER_F;
-    const f4 *W1p = (const f4 *)hw, *W2p = (const f4 *)(hw + W1_F + Q);
-    const float *b1 = hw + W1_F, *b2 = hw + W1_F + Q + W2_F;
+    // C = 64: the embedding tables (128 KB) live in LDS and conv1's weights in registers.
+    // C = 128: the tables are 256 KB, so they stay in L2 (two 512-B rows per step) and LDS
+    // holds conv1's weights instead (its 64 inputs per thread would not fit the registers
+    // next to conv2's 128).
+    constexpr bool TABLES_IN_LDS = CC == 64;
+    constexpr int W1N4 = P::W1N / 4;         // float4 of conv1 weights per thread
+    float *big = smem;                        // tables [2][Q][C] or conv1 weights [W1N4][512] f4
+    float *a0 = smem + 32768;                 // [C]
+    float *a1 = a0 + C;                       // [256]
+    float *lgb = a1 + Q;                      // [256] logits
+    const float *E0 = TABLES_IN_LDS ? big : a.w, *E1 = E0 + Q * C;
+    const float *hw = a.w + P::EMB_F + (size_t)L * P::LAYER_F;
+    const f4 *W1p = (const f4 *)hw, *W2p = (const f4 *)(hw + P::W1_F + Q);
+    const float *b1 = hw + P::W1_F, *b2 = hw + P::W1_F + Q + P::W2_F;
     int32_t *samples = a.samples + (size_t)b * a.stride;
 
-    {
-      const f4 *src = (const f4 *)a.w;
-      f4 *dst = (f4 *)E0;
-      for (int i = tid; i < EMB_F / 4; i += NT) dst[i] = src[i];
-    }
-    // conv1: thread (o1 = tid>>1, q1 = tid&1), 32 inputs; conv2: thread (og = tid>>3, q2 = tid&7),
-    // 4 outputs x 32 inputs
+    // conv1: thread (o1 = tid>>1, q1 = tid&1), C/2 inputs; conv2: thread (og = tid>>3,
+    // q2 = tid&7), 4 outputs x 32 inputs
     const int o1 = tid >> 1, q1 = tid & 1, og = tid >> 3, q2 = tid & 7;
-    v2f w1[16], w2[4][16];
-    load32(w1, W1p, NT, tid);
+    v2f w1[TABLES_IN_LDS ? 2 * W1N4 : 2], w2[4][16];
+    if constexpr (TABLES_IN_LDS) {
+      const f4 *src = (const f4 *)a.w;
+      f4 *dst = (f4 *)big;
+      for (int i = tid; i < P::EMB_F / 4; i += NT) dst[i] = src[i];
+      loadn<W1N4>(w1, W1p, NT, tid);
+    } else {
+      for (int i = tid; i < W1N4 * NT; i += NT) ((f4 *)big)[i] = W1p[i];
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) load32(w2[r], W2p + r * 8 * NT, NT, tid);
+    for (int r = 0; r < 4; ++r) loadn<8>(w2[r], W2p + r * 8 * NT, NT, tid);
     const float b1r = b1[o1];
     const float b2r = b2[4 * og + (q2 & 3)];
     __syncthreads();
@@ -444,12 +572,16 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
     // one-hot input) and hands them to stage 0, so no barrier sits between the choice
     // and the next step's first hop.
     int idx_cur = 0, idx_prev = -1;
-    auto send_h0 = [&](unsigned ep) {  // wave 0: granule `lane` = residual, 64+lane = skip sum 0
+    auto send_h0 = [&](unsigned ep) {  // wave 0: granules c = residual, C + c = skip sum 0
       const int ic = min(max(idx_cur, 0), Q - 1), ip = min(idx_prev, Q - 1);
-      float v = E1[ic * C + lane];
-      if (ip >= 0) v += E0[ip * C + lane];
-      put_granule(outbox + lane, ep, v, fast_edge);
-      put_granule(outbox + 64 + lane, ep, 0.f, fast_edge);
+#pragma unroll
+      for (int j = 0; j < C / 64; ++j) {
+        const int ch = lane + 64 * j;
+        float v = E1[ic * C + ch];
+        if (ip >= 0) v += E0[ip * C + ch];
+        put_granule(outbox + ch, ep, v, fast_edge);
+        put_granule(outbox + C + ch, ep, 0.f, fast_edge);
+      }
     };
     if (wave == 0) {
       idx_cur = samples[a.t_begin];
@@ -466,11 +598,19 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       int next_idx = 0;
       if (wave == 0) {
         if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
-        float v0, v1;
-        const bool ok = wait_inbox(inbox, epoch, err, v0, v1);
-        if (ok && lane >= 32) {
-          a0[2 * lane - 64] = leaky(v0);
-          a0[2 * lane - 63] = leaky(v1);
+        float v[GL];
+        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
+        if (ok) {
+          // only the skip sum (granules C..2C-1) feeds the head
+          if (GL == 2) {
+            if (lane >= 32) {
+              a0[2 * (lane - 32)] = leaky(v[0]);
+              a0[2 * (lane - 32) + 1] = leaky(v[1]);
+            }
+          } else {
+            a0[2 * lane] = leaky(v[GL - 2]);
+            a0[2 * lane + 1] = leaky(v[GL - 1]);
+          }
         }
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
@@ -478,14 +618,23 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
       MVN_STAMP(b, s, ts - a.t_begin, 0);
       if (do_head) {
         {
-          float hsum = dot32(w1, a0 + 32 * q1);
+          float hsum;
+          if constexpr (TABLES_IN_LDS) {
+            f4 x[W1N4];
+            ldsn<W1N4>(x, a0 + P::W1N * q1);
+            hsum = dotn<W1N4>(w1, x);
+          } else {
+            hsum = dot_stream<W1N4>((const f4 *)big, NT, tid, a0 + P::W1N * q1);
+          }
           hsum += dpp_mov<DPP_XOR1>(hsum);
           if (q1 == 0) a1[o1] = leaky(hsum + b1r);
         }
         lds_barrier();
         {
-          float s0 = dot32(w2[0], a1 + 32 * q2), s1 = dot32(w2[1], a1 + 32 * q2);
-          float s2 = dot32(w2[2], a1 + 32 * q2), s3 = dot32(w2[3], a1 + 32 * q2);
+          f4 x[8];
+          ldsn<8>(x, a1 + 32 * q2);
+          float s0 = dotn<8>(w2[0], x), s1 = dotn<8>(w2[1], x);
+          float s2 = dotn<8>(w2[2], x), s3 = dotn<8>(w2[3], x);
           s0 = quad_sum(s0); s0 += other_quad(s0);
           s1 = quad_sum(s1); s1 += other_quad(s1);
           s2 = quad_sum(s2); s2 += other_quad(s2);
@@ -591,123 +740,146 @@ __global__ __launch_bounds__(512, 2) void gen_pipe64_kernel(GenArgs a, u64 *hand
 }
 
 // ---- packing: state_dict layouts -> per-thread register order -----------------
-__global__ void pack_layer_p64_kernel(const float *fw, const float *gw, const float *rw,
-                                      const float *rb, const float *sw, const float *sb,
-                                      float *__restrict__ dst) {
-  using namespace p64;
+template <int CC>
+__global__ void pack_layer_pipe_kernel(const float *fw, const float *gw, const float *rw,
+                                       const float *rb, const float *sw, const float *sb,
+                                       float *__restrict__ dst) {
+  using P = PipeCfg<CC>;
+  constexpr int C = P::C, MAT_F = P::MAT_F, NF4 = P::NF4, KQ = P::KQ, KPER = P::KPER;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= LAYER_F) return;
+  if (i >= P::LAYER_F) return;
   if (i >= 3 * MAT_F) {
     const int o = i - 3 * MAT_F;
     dst[i] = o < C ? rb[o] : sb[o - C];
     return;
   }
-  // each matrix: [i8 (8)][t (256)] float4; thread t = 4*c + kq owns rows (c, 64+c) x inputs
-  // k = 16*kq + 4*(i8 & 3) + e: float4 0..3 belong to row c, 4..7 to row 64+c
+  // each matrix: [2*NF4][t (256)] float4; thread t = KQ*c + kq owns rows (c, C+c) x inputs
+  // k = KPER*kq + 4*(i4 % NF4) + e: float4 0..NF4-1 belong to row c, NF4..2NF4-1 to row C+c
   const int region = i / MAT_F, r = i - region * MAT_F;
-  const int e = r & 3, v = r >> 2, t = v & 255, i8 = v >> 8;
-  const int row = (i8 >> 2) * 64 + (t >> 2), k = 16 * (t & 3) + 4 * (i8 & 3) + e;
+  const int e = r & 3, v = r >> 2, t = v & 255, i4 = v >> 8;
+  const int row = (i4 / NF4) * C + t / KQ, k = KPER * (t % KQ) + 4 * (i4 % NF4) + e;
   if (region < 2)
-    dst[i] = fg_elem(fw, gw, C, row, region == 0 ? 64 + k : k);  // WC: current tap, WP: past tap
+    dst[i] = fg_elem(fw, gw, C, row, region == 0 ? C + k : k);  // WC: current tap, WP: past tap
   else
     dst[i] = rs_elem(rw, sw, C, row, k);
 }
 
-__global__ void pack_head_p64_kernel(const float *w1, const float *b1, const float *w2,
-                                     const float *b2, float *__restrict__ dst) {
-  using namespace p64;
+template <int CC>
+__global__ void pack_head_pipe_kernel(const float *w1, const float *b1, const float *w2,
+                                      const float *b2, float *__restrict__ dst) {
+  using P = PipeCfg<CC>;
+  constexpr int C = P::C, Q = P::Q, NT = P::NT, W1N = P::W1N;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < W1_F) {
-    const int e = i & 3, v = i >> 2, tid = v & (NT - 1), i8 = v >> 9;
-    dst[i] = w1[(size_t)(tid >> 1) * C + 32 * (tid & 1) + 4 * i8 + e];
-  } else if (i < W1_F + Q) {
-    dst[i] = b1[i - W1_F];
-  } else if (i < W1_F + Q + W2_F) {
-    const int ii = i - W1_F - Q;
+  if (i < P::W1_F) {
+    // conv1: [W1N/4][tid (512)] float4, thread (o1 = tid>>1, q1 = tid&1) owns W1N inputs
+    const int e = i & 3, v = i >> 2, tid = v & (NT - 1), i4 = v >> 9;
+    dst[i] = w1[(size_t)(tid >> 1) * C + W1N * (tid & 1) + 4 * i4 + e];
+  } else if (i < P::W1_F + Q) {
+    dst[i] = b1[i - P::W1_F];
+  } else if (i < P::W1_F + Q + P::W2_F) {
+    const int ii = i - P::W1_F - Q;
     const int e = ii & 3, v = ii >> 2, tid = v & (NT - 1), rest = v >> 9, r = rest >> 3, i8 = rest & 7;
     dst[i] = w2[(size_t)(4 * (tid >> 3) + r) * Q + 32 * (tid & 7) + 4 * i8 + e];
-  } else if (i < HEAD_F) {
-    dst[i] = b2[i - W1_F - Q - W2_F];
+  } else if (i < P::HEAD_F) {
+    dst[i] = b2[i - P::W1_F - Q - P::W2_F];
   }
 }
 
-__global__ void pack_embed_p64_kernel(const float *__restrict__ causal_w, float *__restrict__ dst) {
-  using namespace p64;
+template <int CC>
+__global__ void pack_embed_pipe_kernel(const float *__restrict__ causal_w, float *__restrict__ dst) {
+  using P = PipeCfg<CC>;
+  constexpr int C = P::C, Q = P::Q;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= EMB_F) return;
+  if (i >= P::EMB_F) return;
   const int tap = i / (Q * C), r = i - tap * Q * C, qq = r / C, c = r - qq * C;
   dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
 }
 
-__global__ void pack_ctx_p64_kernel(const float *wcf, const float *bcf, const float *wcg,
-                                    const float *bcg, float *__restrict__ dst) {
-  using namespace p64;
+template <int CC>
+__global__ void pack_ctx_pipe_kernel(const float *wcf, const float *bcf, const float *wcg,
+                                     const float *bcg, float *__restrict__ dst) {
+  using P = PipeCfg<CC>;
+  constexpr int C = P::C, MAT_F = P::MAT_F, NF4 = P::NF4, KQ = P::KQ, KPER = P::KPER;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= CTX_LAYER_F) return;
+  if (i >= P::CTX_LAYER_F) return;
   if (i >= MAT_F) {
     const int o = i - MAT_F;
     dst[i] = o < C ? bcf[o] : bcg[o - C];
     return;
   }
-  // same thread mapping as the current-tap matrix: thread t = 4*c + kq owns rows (c, 64+c)
-  const int e = i & 3, v = i >> 2, t = v & 255, i8 = v >> 8;
-  const int c = t >> 2, k = 16 * (t & 3) + 4 * (i8 & 3) + e;
-  dst[i] = (i8 >> 2) ? wcg[(size_t)c * C + k] : wcf[(size_t)c * C + k];
-}
-
-int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s) {
-  using namespace p64;
-  for (int l = 0; l < n_layers(d); ++l)
-    hipLaunchKernelGGL(pack_ctx_p64_kernel, dim3((CTX_LAYER_F + 255) / 256), dim3(256), 0, s,
-                       p->ctx_filter_w[l], p->ctx_filter_b[l], p->ctx_gate_w[l], p->ctx_gate_b[l],
-                       ctx_section + (size_t)l * CTX_LAYER_F);
-  return check_hip(hipGetLastError(), "pipe_pack_ctx");
+  // same thread mapping as the current-tap matrix: thread t = KQ*c + kq owns rows (c, C+c)
+  const int e = i & 3, v = i >> 2, t = v & 255, i4 = v >> 8;
+  const int c = t / KQ, k = KPER * (t % KQ) + 4 * (i4 % NF4) + e;
+  dst[i] = (i4 / NF4) ? wcg[(size_t)c * C + k] : wcf[(size_t)c * C + k];
 }
 
 bool pipe_ok(const mvn_dims *d) {
-  return d->residual_channels == 64 && d->skip_channels == 64 && d->input_channels == 256 &&
+  const int c = d->residual_channels;
+  return (c == 64 || c == 128) && d->skip_channels == c && d->input_channels == 256 &&
          n_layers(d) >= 1;
 }
-int pipe_stages(const mvn_dims *d) { return (n_layers(d) + p64::LPS - 1) / p64::LPS + 1; }
+static int pipe_lps(const mvn_dims *d) { return d->residual_channels == 64 ? 4 : 1; }
+int pipe_stages(const mvn_dims *d) { return (n_layers(d) + pipe_lps(d) - 1) / pipe_lps(d) + 1; }
+int pipe_max_batch(const mvn_dims *d) {
+  // the kernel's placement: NS <= 32 -> floor(32/NS) pipelines in each of the 8 XCDs,
+  // otherwise one pipeline per group of ceil(NS/32) XCDs
+  const int NS = pipe_stages(d);
+  return NS <= PIPE_XCD_CUS ? 8 * (PIPE_XCD_CUS / NS) : 8 / ((NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS);
+}
 size_t pipe_hand_floats(const mvn_dims *d, int batch) {
-  // batch * NS inboxes of 128 granules (2 floats each), then 16 flag words (error word
+  // batch * NS inboxes of 2C granules (2 floats each), then 16 flag words (error word
   // first) and batch * NS placement words, padded to 64 floats
   const size_t n = (size_t)batch * pipe_stages(d);
-  return n * p64::GRAN * 2 + (16 + n + 63) / 64 * 64;
+  return n * 2 * d->residual_channels * 2 + (16 + n + 63) / 64 * 64;
+}
+size_t pipe_weights_floats(const mvn_dims *d) {
+  const size_t L = n_layers(d);
+  return d->residual_channels == 64 ? PipeCfg<64>::EMB_F + L * PipeCfg<64>::LAYER_F + PipeCfg<64>::HEAD_F
+                                    : PipeCfg<128>::EMB_F + L * PipeCfg<128>::LAYER_F + PipeCfg<128>::HEAD_F;
 }
 
-int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {
-  using namespace p64;
+template <int CC>
+static int pipe_pack_t(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {
+  using P = PipeCfg<CC>;
   const int L = n_layers(d);
-  hipLaunchKernelGGL(pack_embed_p64_kernel, dim3((EMB_F + 255) / 256), dim3(256), 0, s, p->causal_w,
-                     packed);
+  hipLaunchKernelGGL(pack_embed_pipe_kernel<CC>, dim3((P::EMB_F + 255) / 256), dim3(256), 0, s,
+                     p->causal_w, packed);
   for (int l = 0; l < L; ++l)
-    hipLaunchKernelGGL(pack_layer_p64_kernel, dim3((LAYER_F + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(pack_layer_pipe_kernel<CC>, dim3((P::LAYER_F + 255) / 256), dim3(256), 0, s,
                        p->filter_w[l], p->gate_w[l], p->residual_w[l], p->residual_b[l], p->skip_w[l],
-                       p->skip_b[l], packed + EMB_F + (size_t)l * LAYER_F);
-  hipLaunchKernelGGL(pack_head_p64_kernel, dim3((HEAD_F + 255) / 256), dim3(256), 0, s, p->head1_w,
-                     p->head1_b, p->head2_w, p->head2_b, packed + EMB_F + (size_t)L * LAYER_F);
+                       p->skip_b[l], packed + P::EMB_F + (size_t)l * P::LAYER_F);
+  hipLaunchKernelGGL(pack_head_pipe_kernel<CC>, dim3((P::HEAD_F + 255) / 256), dim3(256), 0, s,
+                     p->head1_w, p->head1_b, p->head2_w, p->head2_b,
+                     packed + P::EMB_F + (size_t)L * P::LAYER_F);
   return check_hip(hipGetLastError(), "pipe_pack");
 }
+int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {
+  return d->residual_channels == 64 ? pipe_pack_t<64>(d, p, packed, s) : pipe_pack_t<128>(d, p, packed, s);
+}
 
-int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
-  using namespace p64;
+template <int CC>
+static int pipe_pack_ctx_t(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s) {
+  using P = PipeCfg<CC>;
+  for (int l = 0; l < n_layers(d); ++l)
+    hipLaunchKernelGGL(pack_ctx_pipe_kernel<CC>, dim3((P::CTX_LAYER_F + 255) / 256), dim3(256), 0, s,
+                       p->ctx_filter_w[l], p->ctx_filter_b[l], p->ctx_gate_w[l], p->ctx_gate_b[l],
+                       ctx_section + (size_t)l * P::CTX_LAYER_F);
+  return check_hip(hipGetLastError(), "pipe_pack_ctx");
+}
+int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s) {
+  return d->residual_channels == 64 ? pipe_pack_ctx_t<64>(d, p, ctx_section, s)
+                                    : pipe_pack_ctx_t<128>(d, p, ctx_section, s);
+}
+
+template <int CC>
+static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
+  using P = PipeCfg<CC>;
   const int NS = pipe_stages(d);
-  int dev = 0, cus = 0;
-  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return MVN_ERR_LAUNCH;
-  if (check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev),
-                "hipDeviceGetAttribute"))
-    return MVN_ERR_LAUNCH;
-  if (batch * NS > cus) {
-    set_error("PIPE variant needs batch*stages = %d*%d workgroups co-resident, device has %d CUs",
-              batch, NS, cus);
-    return MVN_ERR_UNSUPPORTED;
-  }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void *)gen_pipe64_kernel,
+    int rc = check_hip(hipFuncSetAttribute((const void *)gen_pipe_kernel<CC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                       "hipFuncSetAttribute(gen_pipe64)");
+                       "hipFuncSetAttribute(gen_pipe)");
     if (rc) return rc;
     attr_set = true;
   }
@@ -716,12 +888,29 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hip
   int rc = check_hip(hipMemsetAsync(hand, 0, hand_bytes, s), "hipMemsetAsync(hand-off area)");
   if (rc) return rc;
   u64 *gran = (u64 *)hand;
-  unsigned *err = (unsigned *)(hand + (size_t)batch * NS * GRAN * 2);
-  // grid: ceil(batch/8) groups of NS slots, 8 workgroups (one per XCD) per slot
-  const int groups = (batch + 7) / 8;
-  hipLaunchKernelGGL(gen_pipe64_kernel, dim3(groups * NS * 8), dim3(NT), LDS_FLOATS * sizeof(float),
-                     s, a, gran, err, NS, batch);
+  unsigned *err = (unsigned *)(hand + (size_t)batch * NS * P::GRAN * 2);
+  // grid: 8 workgroups (one per XCD) per slot; see the kernel's (xcd, slot) -> (b, s) map
+  const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS;
+  const int slots = NS <= PIPE_XCD_CUS ? (batch + 7) / 8 * NS : (NS + XS - 1) / XS;
+  hipLaunchKernelGGL(gen_pipe_kernel<CC>, dim3(slots * 8), dim3(P::NT),
+                     P::LDS_FLOATS * sizeof(float), s, a, gran, err, NS, batch);
   return check_hip(hipGetLastError(), "mvn_generate(pipe)");
+}
+
+int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
+  const int NS = pipe_stages(d);
+  int dev = 0, cus = 0;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return MVN_ERR_LAUNCH;
+  if (check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev),
+                "hipDeviceGetAttribute"))
+    return MVN_ERR_LAUNCH;
+  if (cus < 8 * PIPE_XCD_CUS || batch > pipe_max_batch(d)) {
+    set_error("PIPE variant: %d stages per sequence, at most %d sequences co-resident on %d CUs "
+              "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_max_batch(d), cus, batch);
+    return MVN_ERR_UNSUPPORTED;
+  }
+  return d->residual_channels == 64 ? pipe_launch_t<64>(a, d, batch, hand, s)
+                                    : pipe_launch_t<128>(a, d, batch, hand, s);
 }
 
 }  // namespace mvn

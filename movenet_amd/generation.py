@@ -145,8 +145,7 @@ class RingGenerator:
         pipeline not co-resident, e.g. another kernel occupying the CUs)."""
         torch.cuda.current_stream(self.device).synchronize()
         if self.variant == N.GEN_PIPE:
-            n_stage = (self.n_layers + 3) // 4 + 1
-            word = self._queue_floats + self.batch * n_stage * 256  # error word follows the inboxes
+            word = self.lib.mvn_gen_status_offset(self.dims, self.batch)
             if int(self.state[word:word + 1].view(torch.int32)[0].item()) != 0:
                 raise RuntimeError("movenet_amd: PIPE generator hand-off timed out")
 

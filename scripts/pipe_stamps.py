@@ -19,10 +19,15 @@ from movenet_amd import _native as N  # noqa: E402
 from movenet_amd.generation import RingGenerator  # noqa: E402
 from movenet_amd.utils.weights import make_state_dict, synthetic_indices  # noqa: E402
 
-CFG = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+WIDE = "--c128" in sys.argv    # BASELINE config 5: 61 stages, the stamps cover the first 16
+if WIDE:
+    CFG = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
+    B, rf = 4, 6144
+else:
+    CFG = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    B, rf = 16, 3072
 dev = "cuda:0"
 sd = {k: v.to(dev) for k, v in make_state_dict(**CFG, seed=0).items()}
-B, rf = 16, 3072
 g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + 4000, device=dev, variant=N.GEN_PIPE)
 g.prime(synthetic_indices(B, rf, 256, 1234).to(dev))
 g.advance(1000)
@@ -32,7 +37,7 @@ lib = N.lib()
 buf = np.zeros((16, 16, 64, 4), dtype=np.uint64)
 lib.mvn_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.mvn_debug_read_stamps(buf.ctypes.data, buf.size) == 0
-NS = 9
+NS = 16 if WIDE else 9          # stages looked at
 st = buf[:B, :NS, 8:, :2].astype(np.int64)         # (B, NS, steps, {in, out}) wall clock
 ck = buf[:B, :NS, 8:, 2:].astype(np.int64)         # same stamps on the shader clock
 mhz = ((ck[:, :NS - 1, :, 1] - ck[:, :NS - 1, :, 0]) /
@@ -45,7 +50,9 @@ head = (st[:, NS - 1, 1:, 1] - st[:, NS - 1, :-1, 0]) * tick           # head: i
 hops = []
 for s in range(NS):
     nxt = (s + 1) % NS
-    if s == NS - 1:    # head's send at step k is received by stage 0 at step k
+    if WIDE and s == NS - 1:
+        hops.append(np.zeros(1))
+    elif s == NS - 1:    # head's send at step k is received by stage 0 at step k
         d = (st[:, 0, :, 0] - st[:, NS - 1, :, 1]) * tick
     else:
         d = (st[:, nxt, :, 0] - st[:, s, :, 1]) * tick
@@ -55,7 +62,8 @@ print("step period (us): mean %.2f  min %.2f  max %.2f" % (step.mean(), step.min
 for s in range(NS - 1):
     print(f"stage {s}: compute {compute[:, s].mean():6.2f} us   hop to next {hops[s].mean():6.2f} us"
           f" (min {hops[s].min():.2f}, max {hops[s].max():.2f})")
-print(f"head   : compute {head.mean():6.2f} us   hop to stage 0 {hops[NS-1].mean():6.2f} us"
+if not WIDE:
+  print(f"head   : compute {head.mean():6.2f} us   hop to stage 0 {hops[NS-1].mean():6.2f} us"
       f" (min {hops[NS-1].min():.2f}, max {hops[NS-1].max():.2f})")
 print("sum compute %.2f us, sum hops %.2f us" % (compute.mean(0).mean(1).sum() + head.mean(),
                                                sum(h.mean() for h in hops)))
@@ -63,11 +71,12 @@ print("sum compute %.2f us, sum hops %.2f us" % (compute.mean(0).mean(1).sum() +
 fine = np.zeros((16, 16, 64, 8), dtype=np.uint64)
 lib.mvn_debug_read_fine.argtypes = [C.c_void_p, C.c_size_t]
 if lib.mvn_debug_read_fine(fine.ctypes.data, fine.size) == 0:
-    f = fine[:B, :NS - 1, 8:, :7].astype(np.int64)
-    names = ["FG dot32 (LDS reads + FMAs)", "FG reduce + gate + z write", "barrier FG->RS",
-             "RS dot32 (LDS reads + FMAs)", "RS reduce + update + write", "barrier RS->FG"]
+    f = fine[:B, :NS - 1, 8:, :6].astype(np.int64)
+    names = ["FG: x loads, dots, lane sums, gate, z write", "barrier FG->RS (two threads' clocks)",
+             "RS: z loads, dots, lane sums", "RS: residual/skip update (+ hand-off stores)",
+             "barrier RS->FG"]
     print("first layer of a stage, shader cycles (median):")
     for k, nm in enumerate(names):
         d = f[..., k + 1] - f[..., k]
-        print(f"  {nm:32s} {np.median(d):7.0f}")
-    print(f"  {'whole layer':32s} {np.median(f[..., 6] - f[..., 0]):7.0f}")
+        print(f"  {nm:46s} {np.median(d):7.0f}")
+    print(f"  {'whole layer':46s} {np.median(f[..., 5] - f[..., 0]):7.0f}")

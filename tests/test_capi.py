@@ -48,6 +48,19 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_PIPE
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 64) == N.GEN_STREAM
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 64) == N.MVN_ERR_UNSUPPORTED
+    # one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 24) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 25) == N.GEN_STREAM
+    # BASELINE config 5 (60 layers, C=K=128): 61 stages span 2 XCDs -> 4 sequences
+    d5 = N.make_dims(10, 6, 256, 128, 128)
+    assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 4) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 5) == N.GEN_GENERIC
+    n5 = 2 * 256 * 128 + 60 * (6 * 128 * 128 + 2 * 128) + 256 * 128 + 256 + 256 * 256 + 256
+    assert lib.mvn_gen_weights_floats(d5, N.GEN_PIPE) == n5 + 60 * (2 * 128 * 128 + 256)
+    assert lib.mvn_gen_weights_floats(d5, N.GEN_GENERIC) == n5 + 60 * (2 * 128 * 128 + 256)
+    assert lib.mvn_gen_state_floats(d5, 1) == 6138 * 128 + 61 * 512 + 128
+    assert lib.mvn_gen_status_offset(d5, 1) == 6138 * 128 + 61 * 512
+    assert lib.mvn_gen_status_offset(d2, 16) == 16 * (3069 * 64 + 9 * 256)
     d1 = N.make_dims(2, 2, 64, 16, 16)
     assert lib.mvn_gen_variant(d1, N.GEN_AUTO, 2) == N.GEN_GENERIC
     assert lib.mvn_gen_variant(d1, N.GEN_STREAM, 2) == N.MVN_ERR_UNSUPPORTED
@@ -63,6 +76,7 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 9 * 256 + 64
     assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 9 * 256) + 192
     assert lib.mvn_gen_state_floats(d1, 2) == 2 * 6 * 16
+    assert lib.mvn_gen_status_offset(d1, 2) == 2 ** 64 - 1
 
 
 def test_bad_arguments_are_refused_before_any_launch():

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from helpers import cfg_of, one_hot, rel_err, synthetic_indices, weights_of
+from movenet_amd import _native as N
 from oracle import wavenet_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -169,10 +170,11 @@ def test_bad_input_raises():
         model.generate(torch.zeros(1, 64, 20), n_samples=30)
 
 
-def test_config5_shape_generate_vs_oracle():
-    """BASELINE config 5's model (60 layers, C=K=128, RF=6144) through the GENERIC fp32
-    kernel: greedy free run == the CPU ring oracle, logits within tolerance of it.
-    (A tuned fp16-operand kernel for this shape is future work: DESIGN.md section 7.)"""
+@pytest.mark.parametrize("variant", [N.GEN_GENERIC, N.GEN_PIPE])
+def test_config5_shape_generate_vs_oracle(variant):
+    """BASELINE config 5's model (60 layers, C=K=128, RF=6144), fp32: greedy free run ==
+    the CPU ring oracle, logits within tolerance of it -- through the GENERIC kernel and
+    through the 61-stage PIPE kernel (one layer per CU, two XCDs per sequence)."""
     from movenet_amd.utils.weights import make_state_dict
     cfg = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
     sd = make_state_dict(**cfg, seed=2, gain=1.5, head_gain=6.0)
@@ -180,10 +182,30 @@ def test_config5_shape_generate_vs_oracle():
     rf, n_new, B = dims.receptive_fields, 12, 1
     pidx = synthetic_indices(B, rf, 256, 5)
     want, want_logits = O.generate_ring(sd, dims, pidx.numpy(), rf + n_new)
-    g = _gen(cfg, sd, B, rf + n_new)
+    g = _gen(cfg, sd, B, rf + n_new, variant=variant)
+    assert g.variant == variant
     g.prime(pidx.to(DEV))
     g.advance(n_new)
     g.check_errors()
     assert np.array_equal(g.samples.cpu().numpy(), want)
     _, logits = g.teacher_forced(torch.from_numpy(want).to(DEV), logits_t0=rf)
     assert rel_err(logits.cpu().numpy(), want_logits) < LOGIT_TOL
+
+
+def test_config5_pipe_matches_generic_over_a_long_run():
+    """Four config-5 sequences (the most the 61-stage pipelines fit), ring priming without
+    the forward kernels, 300 greedy steps: PIPE and GENERIC choose identical samples."""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
+    sd = make_state_dict(**cfg, seed=4, gain=1.5, head_gain=6.0)
+    rf, n_new, B = O.Dims(**cfg).receptive_fields, 300, 4
+    pidx = synthetic_indices(B, rf, 256, 9).to(DEV)
+    runs = {}
+    for variant in (N.GEN_GENERIC, N.GEN_PIPE):
+        g = _gen(cfg, sd, B, rf + n_new, variant=variant)
+        g.prime(pidx)
+        g.advance(n_new)
+        g.check_errors()
+        runs[variant] = g.samples.clone()
+    assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_GENERIC])
+    assert len(torch.unique(runs[N.GEN_PIPE][:, rf:])) > 4
