@@ -283,6 +283,234 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Op op, int nblk_n, int ch
   }
 }
 
+
+// ======================================================================
+// wgrad2: the same product with 16-byte operand traffic end to end, for ops that
+// provide row-vector accessors (a4/x4: four consecutive time steps of one row).
+// Block tile 128(m) x 64*NB(n), four waves as 2 x 2, wave tile 64 x 32*NB (2 x NB MFMA
+// tiles): per 64 time steps a workgroup moves (128 + 64*NB) x 256 B for 64 x 2*NB
+// MFMAs per wave -- half the bytes per MFMA of the 64 x 64 tiling, and no operand is
+// fetched by two workgroups of the same time chunk.  LDS rows keep TIME contiguous
+// (as in HBM: no transpose), padded to 68 floats; a lane fetches its MFMA operands
+// for four k-steps with one ds_read_b128 -- the k index inside a group of 8 time
+// steps is permuted (MFMA j pairs t = 8g+j with t = 8g+4+j), which a sum over time
+// does not see.  One LDS buffer: the next tile waits in registers during the MFMAs.
+// ======================================================================
+constexpr int W2_T = 64;       // time per LDS tile
+constexpr int W2_LD = 68;      // row pitch: conflict-free ds_read_b128 (4 i mod 64 distinct over 16 rows)
+constexpr int W2_CHUNK = 512;  // time per workgroup (512 workgroups at config 2)
+
+// dword-aligned 16-byte global load (the dilation shift t - d is not a multiple of 4 for d < 4)
+__device__ __forceinline__ f4 ldg4(const float *p) {
+  typedef float v4 __attribute__((ext_vector_type(4), aligned(4)));
+  const v4 v = *(const v4 *)p;
+  return f4{v.x, v.y, v.z, v.w};
+}
+// Operand rows of wgrad2 are described by a pointer `p` with p[t] = the row's value at
+// absolute time t (dilation / skip-axis shifts folded into p) and a validity range
+// [lo, hi) outside which the operand is zero; a row that does not exist has lo = hi = 0
+// and any dereferenceable p.  ld4_edge is the masked form for tiles that touch a range
+// end: clamped addresses, values selected afterwards (no exec-mask branches).
+__device__ __forceinline__ f4 ld4_edge(const float *p, int t, int lo, int hi) {
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    // multiply by 0/1 rather than select: a select lets the compiler sink the load into a
+    // conditional block, i.e. one exec-mask branch and one vmcnt(0) per element
+    const int tt = t + e, tc = max(min(tt, hi - 1), lo);
+    v[e] = p[tc] * ((tt >= lo && tt < hi) ? 1.0f : 0.0f);
+  }
+  return f4{v[0], v[1], v[2], v[3]};
+}
+
+template <class Op, int NB>
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int chunks_per_b,
+                                                       float *__restrict__ bias_part, int m_rows_pad,
+                                                       float *__restrict__ part, int n_cols_pad) {
+  __shared__ __attribute__((aligned(16))) float As[128][W2_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[64 * NB][W2_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tb = (op.t_begin & ~3) + ch * W2_CHUNK, te = min(op.t_end, tb + W2_CHUNK);
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: thread -> row (tid >> 4) + 16 p, columns 4 (tid & 15) .. +3
+  const int srow = tid >> 4, st = 4 * (tid & 15);
+  f4 areg[8], xreg[4 * NB];
+  float bsum[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
+  auto gload = [&](int t0) {
+    // one test per tile: does every row of this wave cover the whole tile?  Then sixteen
+    // back-to-back 16-byte loads; otherwise the masked form (first/last tiles, rows that
+    // start later such as the skip gradient, padding rows)
+    // (row pointers are rebuilt per tile behind an optimisation fence: hoisted out of the
+    // loop they would occupy 32-48 registers next to 64 accumulators and 64 staging registers)
+    int srow_q = srow;
+    asm volatile("" : "+v"(srow_q));
+    const float *ap[8], *xp[4 * NB], *xq[4 * NB];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) ap[p] = op.a_ptr(b, mblk * 128 + 16 * p + srow_q);
+#pragma unroll
+    for (int p = 0; p < 4 * NB; ++p) {
+      xp[p] = op.x_ptr(b, nblk * 64 * NB + 16 * p + srow_q);
+      xq[p] = Op::X_PRODUCT ? op.x_ptr2(b, nblk * 64 * NB + 16 * p + srow_q) : nullptr;
+    }
+    bool inter = t0 + W2_T <= te;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int m = mblk * 128 + 16 * p + srow;
+      inter = inter && t0 >= op.a_lo(m) && t0 + W2_T <= op.a_hi(m);
+    }
+#pragma unroll
+    for (int p = 0; p < 4 * NB; ++p) {
+      const int n = nblk * 64 * NB + 16 * p + srow;
+      inter = inter && t0 >= op.x_lo(n) && t0 + W2_T <= op.x_hi(n);
+    }
+    const int t = t0 + st;
+    if (__all(inter)) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) areg[p] = ldg4(ap[p] + t);
+#pragma unroll
+      for (int p = 0; p < 4 * NB; ++p) {
+        xreg[p] = ldg4(xp[p] + t);
+        if (Op::X_PRODUCT) {
+          const f4 v = ldg4(xq[p] + t);
+          xreg[p] = f4{xreg[p].x * v.x, xreg[p].y * v.y, xreg[p].z * v.z, xreg[p].w * v.w};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int m = mblk * 128 + 16 * p + srow;
+        areg[p] = ld4_edge(ap[p], t, op.a_lo(m), min(op.a_hi(m), te));
+      }
+#pragma unroll
+      for (int p = 0; p < 4 * NB; ++p) {
+        const int n = nblk * 64 * NB + 16 * p + srow;
+        const int lo = op.x_lo(n), hi = min(op.x_hi(n), te);
+        xreg[p] = ld4_edge(xp[p], t, lo, hi);
+        if (Op::X_PRODUCT) {
+          const f4 v = ld4_edge(xq[p], t, lo, hi);
+          xreg[p] = f4{xreg[p].x * v.x, xreg[p].y * v.y, xreg[p].z * v.z, xreg[p].w * v.w};
+        }
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      *(f4 *)&As[16 * p + srow][st] = areg[p];
+      if (Op::HAS_BIAS)  // bias gradient = row sums of A
+        bsum[p] += (areg[p].x + areg[p].y) + (areg[p].z + areg[p].w);
+    }
+#pragma unroll
+    for (int p = 0; p < 4 * NB; ++p) *(f4 *)&Xs[16 * p + srow][st] = xreg[p];
+  };
+
+  gload(tb);
+  lstore();
+  __syncthreads();
+  const int h4 = 4 * (lane >> 5), li = lane & 31;
+  for (int t0 = tb; t0 < te; t0 += W2_T) {
+    const bool more = t0 + W2_T < te;
+    if (more) gload(t0 + W2_T);  // next tile's global loads fly under this tile's MFMAs
+    // (fence: the scheduler otherwise hoists the row sums of lstore() above the MFMAs and
+    // waits for the loads it has just issued)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < W2_T / 8; ++g) {
+      f4 a[2], x[NB];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f4 *)&As[64 * wm + 32 * mi + li][8 * g + h4];
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) x[ni] = *(const f4 *)&Xs[32 * NB * wn + 32 * ni + li][8 * g + h4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NB; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(a[mi], j), f4_get(x[ni], j),
+                                                               acc[mi][ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave has read this tile
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mblk * 128 + 64 * wm + 32 * mi + acc_row(r, lane);
+        const int n = nblk * 64 * NB + 32 * NB * wn + 32 * ni + li;
+        if (part) {  // this workgroup's slab; slab_reduce_kernel adds the slabs up in a fixed order
+          part[((size_t)blockIdx.x * m_rows_pad + m) * n_cols_pad + n] = acc[mi][ni][r];
+        } else {
+          float *dst = op.dw(m, n);
+          if (dst) atomicAdd(dst, acc[mi][ni][r]);
+        }
+      }
+  if (Op::HAS_BIAS && nblk == 0 && bias_part) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      float v = bsum[p];  // 16 lanes share a row
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if ((tid & 15) == 0) bias_part[(size_t)blockIdx.x * m_rows_pad + mblk * 128 + 16 * p + srow] = v;
+    }
+  }
+}
+
+// dW(m,n) += sum over the workgroups' slabs, in a fixed order (deterministic, and ~10x cheaper
+// than the 8 M float atomics the slabs replace at config 2).  Workgroup = 32 elements x 8
+// slab segments; one thread per element does the final read-modify-write.
+template <class Op>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(Op op, const float *__restrict__ part,
+                                                          int nparts, int m_rows_pad, int n_cols_pad) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const size_t mn = (size_t)m_rows_pad * n_cols_pad;
+  const size_t idx = (size_t)blockIdx.x * 32 + e;
+  const int per = (nparts + 7) / 8, p0 = seg * per, p1 = min(nparts, p0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = p0;
+  for (; q + 3 < p1; q += 4) {
+    s0 += part[(size_t)q * mn + idx];
+    s1 += part[(size_t)(q + 1) * mn + idx];
+    s2 += part[(size_t)(q + 2) * mn + idx];
+    s3 += part[(size_t)(q + 3) * mn + idx];
+  }
+  for (; q < p1; ++q) s0 += part[(size_t)q * mn + idx];
+  red[seg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (seg == 0) {
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][e];
+    const int m = (int)(idx / n_cols_pad), n = (int)(idx - (size_t)m * n_cols_pad);
+    float *dst = op.dw(m, n);
+    if (dst) *dst += t;
+  }
+}
+
 // one wave per bias word: lane-strided partial sums in a fixed order, then a wave sum
 template <class Op>
 __global__ void bias_reduce_kernel(Op op, const float *__restrict__ bias_part, int nparts,
@@ -335,5 +563,30 @@ static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, float 
                        chunks * batch, mb * 64);
 }
 
+// bias_scratch: >= chunks*batch*128*ceil(m_rows/128) floats when the op has biases, else NULL
+// (wgrad2 has no atomic bias path: an op with biases must be given the scratch).
+// slab_scratch (slab_floats long): room for one m x n slab per workgroup; when it is too
+// small the tiles are combined with float atomics instead.  Op::dw must map distinct (m,n)
+// to distinct words for the slab path.
+template <int NB, class Op>
+static void launch_wgrad2(const Op &op, int m_rows, int n_rows, int batch, float *bias_scratch,
+                          float *slab_scratch, size_t slab_floats, hipStream_t s) {
+  const int nt = op.t_end - (op.t_begin & ~3);
+  if (op.t_end <= op.t_begin || batch <= 0) return;
+  const int chunks = (nt + W2_CHUNK - 1) / W2_CHUNK;
+  const int mb = (m_rows + 127) / 128, nb = (n_rows + 64 * NB - 1) / (64 * NB);
+  const int mpad = mb * 128, npad = nb * 64 * NB;
+  const size_t need = (size_t)chunks * batch * mpad * npad;
+  float *part = (slab_scratch && need <= slab_floats) ? slab_scratch : nullptr;
+  dim3 grid(chunks * batch, mb * nb);
+  hipLaunchKernelGGL((wgrad2_kernel<Op, NB>), grid, dim3(256), 0, s, op, nb, chunks, bias_scratch,
+                     mpad, part, npad);
+  if (part)
+    hipLaunchKernelGGL(slab_reduce_kernel<Op>, dim3(mpad * npad / 32), dim3(256), 0, s, op, part,
+                       chunks * batch, mpad, npad);
+  if (bias_scratch)
+    hipLaunchKernelGGL(bias_reduce_kernel<Op>, dim3(mpad), dim3(64), 0, s, op, bias_scratch,
+                       chunks * batch, mpad);
+}
 
 }  // namespace mvn

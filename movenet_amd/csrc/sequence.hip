@@ -312,6 +312,21 @@ struct WgFgOpT {
     if (n >= 2 * C) return (HAS_CTX && n < 3 * C) ? *ctx.at(b, n - 2 * C, t) : 0.f;
     return n < C ? *xin.at(b, n, t - d) : *xin.at(b, n - C, t);
   }
+  // row descriptors for wgrad2 (gemm_family.h): p[t] = value at absolute time t
+  static constexpr bool X_PRODUCT = false;
+  static constexpr bool HAS_BIAS = HAS_CTX;  // only the context convs carry biases
+  __device__ __forceinline__ const float *a_ptr(int b, int m) const { return dfg.at(b, min(m, 2 * C - 1), 0); }
+  __device__ __forceinline__ int a_lo(int m) const { return m < 2 * C ? t_begin : 0; }
+  __device__ __forceinline__ int a_hi(int m) const { return m < 2 * C ? t_end : 0; }
+  __device__ __forceinline__ const float *x_ptr(int b, int n) const {
+    if (HAS_CTX && n >= 2 * C) return ctx.at(b, min(n - 2 * C, C - 1), 0);
+    const int nc = min(n, 2 * C - 1);
+    // the past tap reads t - d >= t_begin - d >= 0
+    return nc < C ? xin.at(b, nc, 0) - d : xin.at(b, nc - C, 0);
+  }
+  __device__ __forceinline__ const float *x_ptr2(int, int) const { return nullptr; }
+  __device__ __forceinline__ int x_lo(int n) const { return n < (HAS_CTX ? 3 : 2) * C ? t_begin : 0; }
+  __device__ __forceinline__ int x_hi(int n) const { return n < (HAS_CTX ? 3 : 2) * C ? t_end : 0; }
   __device__ __forceinline__ float *dw(int m, int n) const {
     if (m >= 2 * C) return nullptr;
     const int o = m < C ? m : m - C;
@@ -369,16 +384,29 @@ struct WgRsOp {
     return 0.f;
   }
   __device__ __forceinline__ float x(int b, int n, int t) const {
-#if defined(MVN_EXP) && MVN_EXP == 6
-    return n < C ? *th.at(b, n, t) : 0.f;
-#else
     return n < C ? *th.at(b, n, t) * *sg.at(b, n, t) : 0.f;
-#endif
   }
+  // row descriptors for wgrad2: dskip's column axis is t - t_base, valid from t_skip0
+  static constexpr bool X_PRODUCT = true;  // z = th * sg
+  static constexpr bool HAS_BIAS = true;
+  __device__ __forceinline__ const float *a_ptr(int b, int m) const {
+    if (m < C) return dxo.p ? dxo.at(b, m, 0) : dskip.at(b, 0, 0);  // absent row: p[0] must exist
+    if (m < C + Kc) return dskip.at(b, m - C, 0) - t_base;
+    return dskip.at(b, 0, 0);
+  }
+  __device__ __forceinline__ int a_lo(int m) const {
+    if (m < C) return dxo.p ? t_begin : 0;
+    return m < C + Kc ? max(t_begin, t_skip0) : 0;
+  }
+  __device__ __forceinline__ int a_hi(int m) const {
+    if (m < C) return dxo.p ? t_end : 0;
+    return m < C + Kc ? t_end : 0;
+  }
+  __device__ __forceinline__ const float *x_ptr(int b, int n) const { return th.at(b, min(n, C - 1), 0); }
+  __device__ __forceinline__ const float *x_ptr2(int b, int n) const { return sg.at(b, min(n, C - 1), 0); }
+  __device__ __forceinline__ int x_lo(int n) const { return n < C ? t_begin : 0; }
+  __device__ __forceinline__ int x_hi(int n) const { return n < C ? t_end : 0; }
   __device__ __forceinline__ float *dw(int m, int n) const {
-#if defined(MVN_EXP) && MVN_EXP == 7
-    return nullptr;
-#endif
     if (n >= C) return nullptr;
     if (m < C) return dxo.p ? dwr + (size_t)m * C + n : nullptr;
     if (m < C + Kc) return dws + (size_t)(m - C) * C + n;
@@ -663,6 +691,16 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     const size_t have = (size_t)batch * 2 * C * g.Tp;
     if (need_head > have || need_layer > have) bias_scratch = nullptr;
   }
+  // per-workgroup partial tiles of the layer weight gradients: da1 is dead once the head's
+  // backward below has run
+  float *slab = bwd->da1;
+  const size_t slab_floats = (size_t)batch * Q * g.Sp;
+  // the residual/skip weight gradient runs as wgrad2 (128-row blocks, its own chunking)
+  float *bias_scratch2 = bwd->dfg;
+  {
+    const size_t need = (size_t)((T + 3 + W2_CHUNK - 1) / W2_CHUNK) * batch * ((C + Kc + 127) / 128 * 128);
+    if (need > (size_t)batch * 2 * C * g.Tp) bias_scratch2 = nullptr;
+  }
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
@@ -732,7 +770,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     wr.dxo = dxo; wr.dskip = dskip; wr.th = th; wr.sg = sg;
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
-    launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s);
+    if (bias_scratch2)
+      launch_wgrad2<1>(wr, C + Kc, C, batch, bias_scratch2, slab, slab_floats, s);
+    else
+      launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s);
     DzOp dz;
     dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
     dz.t_base = g.t_base;
@@ -744,7 +785,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
       wf.dwcf = has_ctx ? gr->ctx_filter_w[l] : nullptr; wf.dwcg = has_ctx ? gr->ctx_gate_w[l] : nullptr;
       wf.dbcf = has_ctx ? gr->ctx_filter_b[l] : nullptr; wf.dbcg = has_ctx ? gr->ctx_gate_b[l] : nullptr;
-      launch_wgrad(wf, 2 * C, has_ctx ? 3 * C : 2 * C, batch, has_ctx ? ctx_bias_scratch : nullptr, s);
+      if (!has_ctx)
+        launch_wgrad2<2>(wf, 2 * C, 2 * C, batch, nullptr, slab, slab_floats, s);
+      else
+        launch_wgrad(wf, 2 * C, 3 * C, batch, ctx_bias_scratch, s);
     };
     if (has_ctx) run_wf(WgFgOpT<true>()); else run_wf(WgFgOpT<false>());
     if (has_ctx) {
