@@ -22,10 +22,12 @@ STAMP = os.path.join(LIB_DIR, "libmovenet_hip.stamp")
 SOURCES = ["common.hip", "generate.hip", "generate_pipe.hip", "sequence.hip", "video.hip"]
 HEADERS = ["common.h", "gen_common.h", "gemm_family.h", os.path.join(ROOT, "include", "movenet_hip.h")]
 FLAGS = [
-    "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
     "-ffp-contract=off",  # keep every mul/add as written: the kernels spell out fmaf themselves
 ]
+# Per-source extra flags (none at present; e.g. {"sequence.hip": ["-fno-slp-vectorize"]}).
+EXTRA_FLAGS: dict = {}
 
 
 def _hipcc() -> str:
@@ -44,8 +46,46 @@ def _digest() -> str:
     for p in _source_paths() + [p if os.path.isabs(p) else os.path.join(HERE, p) for p in HEADERS]:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
+
+
+def _compile_and_link(out: str, defs: List[str], keep_temps: bool, verbose: bool) -> None:
+    """One hipcc -c per source (in parallel, each with its own flags), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(LIB_DIR, "obj_" + os.path.basename(out).replace(".so", ""))
+    os.makedirs(objdir, exist_ok=True)
+    base = [_hipcc()] + FLAGS + defs + ["-I", os.path.join(ROOT, "include"), "-I", HERE]
+    if keep_temps:
+        base += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+
+    def one(src: str):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = base + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
+        if verbose:
+            print("[movenet_amd] " + " ".join(cmd), flush=True)
+        return obj, subprocess.run(cmd, cwd=LIB_DIR, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(one, SOURCES))
+    for obj, proc in results:
+        if proc.returncode != 0:
+            sys.stderr.write(proc.stdout + proc.stderr)
+            raise RuntimeError(f"hipcc failed compiling {obj}")
+        if verbose and (proc.stderr.strip() or proc.stdout.strip()):
+            print(proc.stdout + proc.stderr)
+    link = [_hipcc(), "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"]
+    link += [obj for obj, _ in results] + ["-o", out]
+    if verbose:
+        print("[movenet_amd] " + " ".join(link), flush=True)
+    proc = subprocess.run(link, cwd=LIB_DIR, capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout + proc.stderr)
+        raise RuntimeError(f"hipcc failed linking {out}")
+    if keep_temps:  # the .s files land next to the objects: keep them where they used to be
+        for f in os.listdir(objdir):
+            if f.endswith(".s"):
+                shutil.copy(os.path.join(objdir, f), os.path.join(LIB_DIR, f))
 
 
 def build_stamps(verbose: bool = True, exp: int = 0) -> str:
@@ -53,15 +93,7 @@ def build_stamps(verbose: bool = True, exp: int = 0) -> str:
     generator (never loaded by the product; see scripts/pipe_stamps.py)."""
     os.makedirs(LIB_DIR, exist_ok=True)
     out = os.path.join(LIB_DIR, "libmovenet_hip_stamps.so" if exp == 0 else f"libmovenet_hip_exp{exp}.so")
-    cmd = [_hipcc()] + FLAGS + ["-DMVN_PIPE_STAMPS", f"-DMVN_EXP={exp}",
-                                "-I", os.path.join(ROOT, "include"), "-I", HERE]
-    cmd += _source_paths() + ["-o", out]
-    if verbose:
-        print("[movenet_amd] " + " ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, cwd=LIB_DIR, capture_output=True, text=True)
-    if proc.returncode != 0:
-        sys.stderr.write(proc.stdout + proc.stderr)
-        raise RuntimeError("hipcc failed building libmovenet_hip_stamps.so")
+    _compile_and_link(out, ["-DMVN_PIPE_STAMPS", f"-DMVN_EXP={exp}"], False, verbose)
     return out
 
 
@@ -72,21 +104,7 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -
         with open(STAMP) as f:
             if f.read().strip() == digest:
                 return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", HERE]
-    if keep_temps:
-        tmp = os.path.join(LIB_DIR, "temps")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-    cmd += _source_paths() + ["-o", LIB_PATH]
-    if verbose:
-        print("[movenet_amd] " + " ".join(cmd), flush=True)
-    cwd = os.path.join(LIB_DIR, "temps") if keep_temps else LIB_DIR
-    proc = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        sys.stderr.write(proc.stdout + proc.stderr)
-        raise RuntimeError("hipcc failed building libmovenet_hip.so")
-    if verbose and (proc.stderr.strip() or proc.stdout.strip()):
-        print(proc.stdout + proc.stderr)
+    _compile_and_link(LIB_PATH, [], keep_temps, verbose)
     with open(STAMP, "w") as f:
         f.write(digest)
     return LIB_PATH

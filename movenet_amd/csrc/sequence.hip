@@ -17,6 +17,8 @@
 //
 // Activations use an ABSOLUTE time axis (see movenet_hip.h): tensor (B, ch, Tp),
 // column t = input time t, layer l's input valid for t >= A_l.
+#include <algorithm>
+
 #include "common.h"
 #include "gemm_family.h"
 
@@ -454,14 +456,35 @@ __global__ void embed_kernel(const float *__restrict__ cw, const int32_t *__rest
   *x0.at(b, c, t) = v;
 }
 
-__global__ void embed_grad_kernel(float *__restrict__ dcw, const int32_t *__restrict__ idx,
-                                  int idx_stride, Act dx0, int C, int Q, int T) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-  if (t >= T) return;
+// Gradient of the causal conv on a one-hot input = a scatter-add of dx0 columns into the two
+// embedding tables (tap 1 at class idx[t], tap 0 at idx[t-1]).  A workgroup owns `cg` channels
+// and EG_CHUNK time steps of one sequence and accumulates them in an LDS copy of its table
+// slice [cg][Q][2] (ds_add_f32: lanes walk t, so a collision needs two lanes of one wave
+// on the same class); the slice is then added to HBM once -- T/EG_CHUNK times fewer
+// global atomics than one per (channel, time step).
+constexpr int EG_CHUNK = 2048;
+__global__ __launch_bounds__(256) void embed_grad_kernel(float *__restrict__ dcw,
+                                                         const int32_t *__restrict__ idx, int idx_stride,
+                                                         Act dx0, int C, int Q, int T, int cg) {
+  extern __shared__ float tab[];  // [cg][Q][2]
+  const int b = blockIdx.z, c0 = blockIdx.y * cg, t0 = blockIdx.x * EG_CHUNK;
+  const int nc = min(cg, C - c0), t1 = min(T, t0 + EG_CHUNK);
+  for (int i = threadIdx.x; i < cg * Q * 2; i += blockDim.x) tab[i] = 0.f;
+  __syncthreads();
   const int32_t *ib = idx + (size_t)b * idx_stride;
-  const float g = *dx0.at(b, c, t);
-  atomicAdd(dcw + ((size_t)c * Q + min(max(ib[t], 0), Q - 1)) * 2 + 1, g);
-  if (t > 0) atomicAdd(dcw + ((size_t)c * Q + min(max(ib[t - 1], 0), Q - 1)) * 2 + 0, g);
+  for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    const int q1 = min(max(ib[t], 0), Q - 1), q0 = t > 0 ? min(max(ib[t - 1], 0), Q - 1) : -1;
+    for (int c = 0; c < nc; ++c) {
+      const float g = *dx0.at(b, c0 + c, t);
+      atomicAdd(&tab[(c * Q + q1) * 2 + 1], g);
+      if (q0 >= 0) atomicAdd(&tab[(c * Q + q0) * 2 + 0], g);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc * Q * 2; i += blockDim.x) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(dcw + (size_t)c0 * Q * 2 + i, v);
+  }
 }
 
 // softmax over channels, in place; one thread per (b, column)
@@ -812,8 +835,15 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     wc.dcw = gr->causal_w;
     launch_wgrad(wc, C, 2 * Q, batch, nullptr, s);
   } else {
-    hipLaunchKernelGGL(embed_grad_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s,
-                       gr->causal_w, index, index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T);
+    // channels per workgroup: the table slice [cg][Q][2] fits 64 KB of LDS
+    if (Q > 8192) {
+      set_error("mvn_backward: input_channels %d > 8192 not supported by the embedding gradient", Q);
+      return MVN_ERR_UNSUPPORTED;
+    }
+    const int cg = std::max(1, std::min(C, 8192 / Q));
+    hipLaunchKernelGGL(embed_grad_kernel, dim3((T + EG_CHUNK - 1) / EG_CHUNK, (C + cg - 1) / cg, batch),
+                       dim3(256), (size_t)cg * Q * 2 * sizeof(float), s, gr->causal_w, index,
+                       index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T, cg);
   }
   return check_hip(hipGetLastError(), "mvn_backward");
 }

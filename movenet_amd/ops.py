@@ -130,7 +130,14 @@ class _WaveNetFunction(torch.autograd.Function):
         sd = dict(zip(names, params))
         dout = dout.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
-            grads = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in sd.items()}
+            # one zero-filled flat buffer, the per-parameter gradients are views into it (one
+            # fill kernel instead of ~190; FlatGradSync all-reduces the buffer in place)
+            sizes = [p.numel() for p in params]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            grads, off = {}, 0
+            for n, p_, k in zip(names, params, sizes):
+                grads[n] = flat[off:off + k].view(p_.shape)
+                off += k
             gp, gkeep = pack_params(dims, grads, L)
             g = N.ParamGrads(gp.causal_w, gp.filter_w, gp.gate_w, gp.residual_w, gp.residual_b,
                              gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b,

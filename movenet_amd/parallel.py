@@ -60,6 +60,27 @@ class FlatGradSync:
                 p.copy_(flat[off:off + n].view_as(p))
                 off += n
 
+    @staticmethod
+    def _contiguous_span(used: List[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+        """One 1-D tensor covering every gradient when they are contiguous views laid out in
+        increasing order inside ONE storage (gaps allowed: parameters without a gradient lie
+        between them and are zero on every rank), else None."""
+        g0 = used[0].grad
+        store = g0.untyped_storage()
+        lo, hi, prev_end = None, None, None
+        for p in used:
+            g = p.grad
+            if (g.dtype != g0.dtype or not g.is_contiguous() or
+                    g.untyped_storage().data_ptr() != store.data_ptr()):
+                return None
+            beg = g.storage_offset()
+            if prev_end is not None and beg < prev_end:
+                return None
+            prev_end = beg + g.numel()
+            lo = beg if lo is None else lo
+            hi = prev_end
+        return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(store, lo, (hi - lo,))
+
     def sync_gradients(self) -> int:
         """Average .grad over ranks; returns the number of floats sent.  The set
         of parameters with a gradient must be the same on every rank (it is: it
@@ -68,6 +89,11 @@ class FlatGradSync:
         n = sum(p.grad.numel() for p in used)
         if self.world <= 1 or n == 0:
             return 0
+        span = self._contiguous_span(used)
+        if span is not None:  # the gradients already lie back to back in one buffer (ops.py)
+            dist.all_reduce(span, op=dist.ReduceOp.SUM)
+            span.div_(self.world)
+            return span.numel()
         if self._flat is None or self._flat.numel() != n or self._flat.device != used[0].grad.device:
             self._flat = torch.empty(n, dtype=used[0].grad.dtype, device=used[0].grad.device)
         off = 0

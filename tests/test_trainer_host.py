@@ -128,8 +128,22 @@ def _dp_worker(rank: int, world: int, port: int, out_dir: str):
     net[2](net[1](net[0](x))).pow(2).sum().backward()  # net[3] unused: its grads stay None
     local = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
     sent = sync.sync_gradients()
+    # second exchange: the same gradients as views of ONE flat buffer with a gap (what
+    # ops.py's backward hands to autograd) -> reduced in place, no staging copies
+    used = [p for p in net.parameters() if p.grad is not None]
+    flat = torch.zeros(sum(p.numel() for p in used) + 11)
+    off = 0
+    for i, (p, g) in enumerate(zip(used, [x for x in local if x is not None])):
+        if i == 2:
+            off += 11  # a parameter without gradient in between
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        p.grad.copy_(g)
+        off += p.numel()
+    assert FlatGradSync._contiguous_span(used) is not None
+    sent_flat = sync.sync_gradients()
     torch.save({"params": [p.detach().clone() for p in net.parameters()], "local": local,
-                "synced": [p.grad for p in net.parameters()], "sent": sent},
+                "synced": [p.grad.clone() if p.grad is not None else None for p in net.parameters()],
+                "sent": sent, "sent_flat": sent_flat},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -142,6 +156,7 @@ def test_data_parallel_gradient_exchange_gloo(tmp_path):
     for a, b in zip(r[0]["params"], r[1]["params"]):
         assert torch.equal(a, b)  # rank 0's weights everywhere
     assert r[0]["sent"] == r[1]["sent"] == 5 * 7 + 7 + 7 * 3 + 3
+    assert r[0]["sent_flat"] == r[1]["sent_flat"] == 5 * 7 + 7 + 7 * 3 + 3 + 11  # the span, gap included
     for i, (g0, g1) in enumerate(zip(r[0]["synced"], r[1]["synced"])):
         if g0 is None:
             assert g1 is None and r[0]["local"][i] is None  # unused parameters are left alone
