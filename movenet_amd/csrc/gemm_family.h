@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_kernel(Op op) {
 // groups of whole rows -- 16-byte, row-contiguous global accesses, no 64-value register
 // epilogue (which spilled ~100 VGPRs to scratch in the residual/skip and dz ops).  Tiles
 // start at a multiple of 4 so that those accesses are aligned; Op::x must return 0 for
-// t < t_begin and Op::store4(b, m, t, v) masks columns outside [t_begin, t_end).
+// t < t_begin; Op::load4(b, m, t) fetches what the store of those four columns needs from
+// HBM (an Op::Pre) and Op::store4(b, m, t, v, pre) masks columns outside [t_begin, t_end).
 typedef float4 f4;
 
 template <class Op>
@@ -173,11 +174,37 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_staged_kernel(Op op) {
         stage[acc_row(r, lane) * 256 + 64 * wave + 32 * ni + (lane & 31)] = acc[mi][ni][r];
     __syncthreads();
     const int c4 = tid & 63, t = t0 + 4 * c4;
-    if (t < op.t_end) {
-      for (int j = 0; j < 8; ++j) {
-        const int row = wave + 4 * j;
-        const f4 v = *(const f4 *)&stage[row * 256 + 4 * c4];
-        op.store4(b, mb * 64 + 32 * mi + row, t, v);
+    if constexpr (Op::FG_PAIRS) {
+      // gated layer: rows [0,16) of this half are filter rows, [16,32) the gate rows of the
+      // same channels; one thread gates four columns of a channel and writes z, tanh, sigmoid
+      if (t < op.t_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wave + 4 * j;
+          op.store_fg(b, mb * 32 + 16 * mi + row, t, *(const f4 *)&stage[row * 256 + 4 * c4],
+                      *(const f4 *)&stage[(16 + row) * 256 + 4 * c4]);
+        }
+      }
+    } else if (t < op.t_end) {
+      // two phases: first every global operand of the eight stores (residual input, skip
+      // accumulator, tanh/sigmoid ...) is requested, then the stores run.  Fused into one
+      // loop each store waited for its own loads: eight HBM round trips in a row per half.
+      // (Op::EPI_BATCH stores per batch: 8, or 4 where two preloaded operands per store would
+      // push the kernel over 128 registers, i.e. from 4 to 3 waves per SIMD)
+      constexpr int EB = Op::EPI_BATCH;
+#pragma unroll
+      for (int j0 = 0; j0 < 8; j0 += EB) {
+        f4 v[EB];
+        typename Op::Pre pre[EB];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+          const int row = wave + 4 * (j0 + j);
+          v[j] = *(const f4 *)&stage[row * 256 + 4 * c4];
+          pre[j] = op.load4(b, mb * 64 + 32 * mi + row, t);
+        }
+#pragma unroll
+        for (int j = 0; j < EB; ++j)
+          op.store4(b, mb * 64 + 32 * mi + wave + 4 * (j0 + j), t, v[j], pre[j]);
       }
     }
     __syncthreads();
@@ -186,6 +213,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_staged_kernel(Op op) {
 
 // column mask helpers for store4: all four columns inside [lo, hi)?
 __device__ __forceinline__ bool cols_full(int t, int lo, int hi) { return t >= lo && t + 3 < hi; }
+struct Pre1 { f4 a; };     // operands preloaded for one store4 (see gemm_wx_staged_kernel)
+struct Pre2 { f4 a, b; };
+constexpr f4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 __device__ __forceinline__ float f4_get(const f4 &v, int e) {
   return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
 }

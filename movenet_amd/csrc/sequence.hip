@@ -40,37 +40,52 @@ struct FgOpT {
   Act xin;               // layer input
   Act ctx;               // upsampled video or p == NULL
   Act z, th, sg;         // outputs (th/sg.p may be NULL)
+  // 64-row block mb = channels [32 mb, 32 mb + 32); inside each 32-row half rows [0,16) are
+  // filter rows and [16,32) the gate rows of the same 16 channels (the LDS-staged epilogue
+  // of gemm_wx_staged_kernel pairs row r with row 16 + r)
+  static constexpr bool FG_PAIRS = true;
   __device__ __forceinline__ float w(int m, int k) const {
-    const int r = m & 63, c = (m >> 6) * 32 + (r & 31);
+    const int r = m & 63, q = r & 31, c = (m >> 6) * 32 + (r >> 5) * 16 + (q & 15);
+    const bool gate_row = q >= 16;
     if (c >= C || k >= K) return 0.f;
-    if (HAS_CTX && k >= 2 * C) return (r < 32 ? wcf : wcg)[(size_t)c * C + (k - 2 * C)];
+    if (HAS_CTX && k >= 2 * C) return (gate_row ? wcg : wcf)[(size_t)c * C + (k - 2 * C)];
     const int tap = k >= C, kc = k - tap * C;
-    const float *src = r < 32 ? wf : wg;
+    const float *src = gate_row ? wg : wf;
     return src[((size_t)c * C + kc) * 2 + tap];
   }
   __device__ __forceinline__ float x(int b, int k, int t) const {
-    if (k >= K || t >= t_end) return 0.f;
+    if (k >= K || t < t_begin || t >= t_end) return 0.f;
     if (HAS_CTX && k >= 2 * C) return *ctx.at(b, k - 2 * C, t);
     return k < C ? *xin.at(b, k, t - d) : *xin.at(b, k - C, t);  // t >= t_begin >= d
   }
-  __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &f,
-                                           const f32x16 &g) const {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = mb * 32 + acc_row(r, lane);
-      if (c < C) {
-        float fv = f[r], gv = g[r];
-        if (HAS_CTX) {
-          fv += bcf[c];
-          gv += bcg[c];
-        }
-        const float tv = tanhf(fv), sv = 1.0f / (1.0f + expf(-gv));
-        *z.at(b, c, t) = tv * sv;
-        if (th.p) {
-          *th.at(b, c, t) = tv;
-          *sg.at(b, c, t) = sv;
-        }
+  __device__ __forceinline__ void store_fg(int b, int c, int t, const f4 &f, const f4 &g) const {
+    if (c >= C) return;
+    float fb = 0.f, gb = 0.f;
+    if (HAS_CTX) {
+      fb = bcf[c];
+      gb = bcg[c];
+    }
+    const f4 tv = f4{tanhf(f.x + fb), tanhf(f.y + fb), tanhf(f.z + fb), tanhf(f.w + fb)};
+    const f4 sv = f4{1.0f / (1.0f + expf(-(g.x + gb))), 1.0f / (1.0f + expf(-(g.y + gb))),
+                     1.0f / (1.0f + expf(-(g.z + gb))), 1.0f / (1.0f + expf(-(g.w + gb)))};
+    const f4 zv = f4{tv.x * sv.x, tv.y * sv.y, tv.z * sv.z, tv.w * sv.w};
+    float *zp = z.at(b, c, t);
+    if (cols_full(t, t_begin, t_end)) {
+      *(f4 *)zp = zv;
+      if (th.p) {
+        *(f4 *)th.at(b, c, t) = tv;
+        *(f4 *)sg.at(b, c, t) = sv;
       }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (t + e >= t_begin && t + e < t_end) {
+          zp[e] = f4_get(zv, e);
+          if (th.p) {
+            th.at(b, c, t)[e] = f4_get(tv, e);
+            sg.at(b, c, t)[e] = f4_get(sv, e);
+          }
+        }
     }
   }
 };
@@ -91,14 +106,27 @@ struct RsOp {
   __device__ __forceinline__ float x(int b, int k, int t) const {
     return (k < C && t >= t_begin && t < t_end) ? *z.at(b, k, t) : 0.f;
   }
-  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+  static constexpr int EPI_BATCH = 8;
+  static constexpr bool FG_PAIRS = false;
+  typedef Pre1 Pre;  // residual input (m < C) or the skip accumulator (m >= C)
+  __device__ __forceinline__ Pre load4(int b, int m, int t) const {
+    Pre p{kZero4};
+    if (m < C) {
+      if (xout.p && cols_full(t, t_begin, t_end)) p.a = *(const f4 *)xin.at(b, m, t);
+    } else if (m < C + Kc) {
+      if (!first_layer && cols_full(t, max(t_begin, t_skip0), t_end))
+        p.a = *(const f4 *)skip.at(b, m - C, t - t_base);
+    }
+    return p;
+  }
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v, const Pre &p) const {
     if (m < C) {
       if (!xout.p) return;
       const float bias = br[m];
       const float *xi = xin.at(b, m, t);
       float *xo = xout.at(b, m, t);
       if (cols_full(t, t_begin, t_end)) {
-        const f4 xv = *(const f4 *)xi;
+        const f4 xv = p.a;
         *(f4 *)xo = f4{(v.x + bias) + xv.x, (v.y + bias) + xv.y, (v.z + bias) + xv.z,
                        (v.w + bias) + xv.w};
       } else {
@@ -113,7 +141,7 @@ struct RsOp {
       if (cols_full(t, lo, t_end)) {
         f4 o = f4{v.x + bias, v.y + bias, v.z + bias, v.w + bias};
         if (!first_layer) {
-          const f4 old = *(const f4 *)sp;
+          const f4 old = p.a;
           o = f4{old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w};
         }
         *(f4 *)sp = o;
@@ -155,14 +183,22 @@ struct DenseOp {
     if (OUT == OUT_BIAS_LRELU) return leaky(v + bv);
     return v * (refv > 0.f ? 1.0f : kLeakySlope);
   }
-  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+  static constexpr int EPI_BATCH = 8;
+  static constexpr bool FG_PAIRS = false;
+  typedef Pre1 Pre;  // the activation whose sign gates the leaky-ReLU derivative
+  __device__ __forceinline__ Pre load4(int b, int m, int t) const {
+    Pre p{kZero4};
+    if (OUT == OUT_MUL_DLRELU && m < M && aligned_out && cols_full(t, t_begin, t_out_end))
+      p.a = *(const f4 *)ref.at(b, m, t);
+    return p;
+  }
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v, const Pre &p) const {
     if (m >= M) return;
     const float bv = OUT == OUT_MUL_DLRELU ? 0.f : bias[m];
     float *yo = yout.at(b, m, t);
     const float *rp = OUT == OUT_MUL_DLRELU ? ref.at(b, m, t) : nullptr;
     if (aligned_out && cols_full(t, t_begin, t_out_end)) {
-      f4 r = f4{0.f, 0.f, 0.f, 0.f};
-      if (OUT == OUT_MUL_DLRELU) r = *(const f4 *)rp;
+      const f4 r = p.a;
       *(f4 *)yo = f4{map(v.x, bv, r.x), map(v.y, bv, r.y), map(v.z, bv, r.z), map(v.w, bv, r.w)};
     } else {
 #pragma unroll
@@ -191,7 +227,11 @@ struct CausalOp {
     if (k < Q) return t > 0 ? *audio.at(b, k, t - 1) : 0.f;
     return *audio.at(b, k - Q, t);
   }
-  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+  static constexpr int EPI_BATCH = 8;
+  static constexpr bool FG_PAIRS = false;
+  typedef Pre1 Pre;  // nothing to preload
+  __device__ __forceinline__ Pre load4(int, int, int) const { return Pre{kZero4}; }
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v, const Pre &) const {
     if (m >= C) return;
     float *o = x0.at(b, m, t);
     if (cols_full(t, t_begin, t_end)) {
@@ -241,12 +281,23 @@ struct DzOp {
     if (k < C + Kc) return t >= t_skip0 ? *dskip.at(b, k - C, t - t_base) : 0.f;
     return 0.f;
   }
-  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &dz) const {
+  static constexpr int EPI_BATCH = 4;
+  static constexpr bool FG_PAIRS = false;
+  typedef Pre2 Pre;  // tanh, sigmoid of the forward pass
+  __device__ __forceinline__ Pre load4(int b, int m, int t) const {
+    Pre p{kZero4, kZero4};
+    if (m < C && cols_full(t, t_begin, t_end)) {
+      p.a = *(const f4 *)th.at(b, m, t);
+      p.b = *(const f4 *)sg.at(b, m, t);
+    }
+    return p;
+  }
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &dz, const Pre &p) const {
     if (m >= C) return;
     const float *tp = th.at(b, m, t), *sp = sg.at(b, m, t);
     float *df = dfg.at(b, m, t), *dg = dfg.at(b, C + m, t);
     if (cols_full(t, t_begin, t_end)) {
-      const f4 tv = *(const f4 *)tp, sv = *(const f4 *)sp;
+      const f4 tv = p.a, sv = p.b;
       *(f4 *)df = f4{dz.x * sv.x * (1.0f - tv.x * tv.x), dz.y * sv.y * (1.0f - tv.y * tv.y),
                      dz.z * sv.z * (1.0f - tv.z * tv.z), dz.w * sv.w * (1.0f - tv.w * tv.w)};
       *(f4 *)dg = f4{dz.x * tv.x * sv.x * (1.0f - sv.x), dz.y * tv.y * sv.y * (1.0f - sv.y),
@@ -281,14 +332,22 @@ struct DxOp {
     if (k < 2 * C) return t >= t_lo ? *dfg.at(b, k, t) : 0.f;
     return t + d < t_end ? *dfg.at(b, k - 2 * C, t + d) : 0.f;
   }
-  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+  static constexpr int EPI_BATCH = 8;
+  static constexpr bool FG_PAIRS = false;
+  typedef Pre1 Pre;  // gradient arriving through the residual connection
+  __device__ __forceinline__ Pre load4(int b, int m, int t) const {
+    Pre p{kZero4};
+    if (m < C && dxo.p && cols_full(t, t_begin, t_end) && t >= t_lo) p.a = *(const f4 *)dxo.at(b, m, t);
+    return p;
+  }
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v, const Pre &p) const {
     if (m >= C) return;
     float *o = dxi.at(b, m, t);
     const float *po = dxo.p ? dxo.at(b, m, t) : nullptr;
     if (cols_full(t, t_begin, t_end) && (!po || t >= t_lo)) {
       f4 r = v;
       if (po) {
-        const f4 u = *(const f4 *)po;
+        const f4 u = p.a;
         r = f4{v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w};
       }
       *(f4 *)o = r;
@@ -358,11 +417,19 @@ struct DctxOp {
   __device__ __forceinline__ float x(int b, int k, int t) const {
     return (k < 2 * C && t >= t_begin && t < t_end) ? *dfg.at(b, k, t) : 0.f;
   }
-  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v) const {
+  static constexpr int EPI_BATCH = 8;
+  static constexpr bool FG_PAIRS = false;
+  typedef Pre1 Pre;  // the context gradient accumulated so far
+  __device__ __forceinline__ Pre load4(int b, int m, int t) const {
+    Pre p{kZero4};
+    if (m < C && cols_full(t, t_begin, t_end)) p.a = *(const f4 *)dctx.at(b, m, t);
+    return p;
+  }
+  __device__ __forceinline__ void store4(int b, int m, int t, const f4 &v, const Pre &p) const {
     if (m >= C) return;
     float *o = dctx.at(b, m, t);
     if (cols_full(t, t_begin, t_end)) {
-      const f4 u = *(const f4 *)o;
+      const f4 u = p.a;
       *(f4 *)o = f4{u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
     } else {
 #pragma unroll
@@ -644,7 +711,7 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
       f.xin = xin; f.z = zv;
       f.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
       f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
-      launch_gemm(f, 2 * ((C + 31) / 32 * 32), batch, s);
+      launch_gemm_staged(f, 2 * ((C + 31) / 32 * 32), batch, s);
     };
     if (has_ctx) run_fg(FgOpT<true>()); else run_fg(FgOpT<false>());
     RsOp r;
