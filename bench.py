@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 CFG = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
 BATCH = 16
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PMC_BYTES_PER_STEP_SEQ = (19762.125 + 13498.8125) * 1024 / (16 * 16000)  # measured, see roofline.traffic
+PMC_BYTES_PER_STEP_SEQ = (19810.6 + 14644.8) * 1024 / (16 * 16000)  # measured, see roofline.traffic
 
 
 def flop_per_sample(cfg) -> int:
@@ -302,10 +302,10 @@ def main():
                 "peak": FP32_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE 19762 KB as
+                # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE 19811 KB as
                 # reported -- 4/8-byte accesses, the guide's x2 correction is calibrated for
-                # 16-B streams only -- + WRITE_SIZE 13499 KB per 16000-step launch of 16
-                # sequences: profiles/r01_pmc_gen_pipe64_fetch_write.csv), scaled to this launch
+                # 16-B streams only -- + WRITE_SIZE 14645 KB per 16000-step launch of 16
+                # sequences: profiles/r01b_pmc_gen_pipe_fetch_write.csv), scaled to this launch
                 "traffic": (PMC_BYTES_PER_STEP_SEQ * BATCH * n_new) if variant_used == 3 else None,
                 "traffic_unit": "bytes per launch (HBM side; the 12.6 MB of dilation queues stay in L2/MALL)",
                 "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>"}[variant_used],

@@ -18,6 +18,7 @@
 // Activations use an ABSOLUTE time axis (see movenet_hip.h): tensor (B, ch, Tp),
 // column t = input time t, layer l's input valid for t >= A_l.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "gemm_family.h"
@@ -648,6 +649,40 @@ static int make_geometry(const mvn_dims *d, int batch, int t_len, Geometry &g) {
 
 }  // namespace mvn
 
+namespace mvn {
+// A second stream per device for the backward pass: the weight gradients of a layer run on
+// it, concurrently with the data gradients on the caller's stream (both read the same
+// tensors: one pass over HBM instead of two, and the tails of one kernel are filled by the
+// other).  Fork/join with events; on return everything is ordered on the caller's stream.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+static int side_stream(SideStream **out) {
+  static SideStream table[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return MVN_ERR_LAUNCH;
+  if (dev < 0 || dev >= 64) {
+    set_error("device ordinal %d out of range", dev);
+    return MVN_ERR_BAD_ARG;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  SideStream &e = table[dev];
+  if (!e.s) {
+    hipStream_t st;
+    if (check_hip(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags"))
+      return MVN_ERR_LAUNCH;
+    for (int i = 0; i < 4; ++i)
+      if (check_hip(hipEventCreateWithFlags(&e.ev[i], hipEventDisableTiming), "hipEventCreateWithFlags"))
+        return MVN_ERR_LAUNCH;
+    e.s = st;
+  }
+  *out = &e;
+  return MVN_OK;
+}
+}  // namespace mvn
+
 using namespace mvn;
 
 extern "C" {
@@ -781,15 +816,16 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     const size_t have = (size_t)batch * 2 * C * g.Tp;
     if (need_head > have || need_layer > have) bias_scratch = nullptr;
   }
-  // per-workgroup partial tiles of the layer weight gradients: da1 is dead once the head's
-  // backward below has run
-  float *slab = bwd->da1;
-  const size_t slab_floats = (size_t)batch * Q * g.Sp;
-  // the residual/skip weight gradient runs as wgrad2 (128-row blocks, its own chunking)
-  float *bias_scratch2 = bwd->dfg;
+  // scratch of the layer weight gradients (wgrad2): per-workgroup partial tiles and bias
+  // partial sums, both in da1, which is dead once the head's backward below has run
+  float *bias_scratch2 = nullptr, *slab = bwd->da1;
+  size_t slab_floats = (size_t)batch * Q * g.Sp;
   {
     const size_t need = (size_t)((T + 3 + W2_CHUNK - 1) / W2_CHUNK) * batch * ((C + Kc + 127) / 128 * 128);
-    if (need > (size_t)batch * 2 * C * g.Tp) bias_scratch2 = nullptr;
+    if (need <= slab_floats / 2) {
+      slab_floats -= need;
+      bias_scratch2 = bwd->da1 + slab_floats;
+    }
   }
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
@@ -848,6 +884,25 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   float *dxo_p = nullptr;  // gradient w.r.t. the layer's residual output
   float *cur = bwd->dx_a, *nxt = bwd->dx_b;
   Act dfg = act_view(bwd->dfg, batch, 2 * C, g.Tp);
+  // Two streams (audio only): per layer  WgRs || Dz  then  WgFg || Dx.
+  //   ev[0]: dx of the previous layer / the head's dskip ready (s -> s2)
+  //   ev[1]: dfg of this layer ready (s -> s2)
+  //   ev[2], ev[3]: WgRs / WgFg done (s2 -> s: the buffers they read may be overwritten)
+  SideStream *side = nullptr;
+  const bool fork = !has_ctx && bias_scratch2;
+  hipStream_t s2 = s;
+  if (fork) {
+    rc = side_stream(&side);
+    if (rc) return rc;
+    s2 = side->s;
+    if (check_hip(hipEventRecord(side->ev[0], s), "hipEventRecord")) return MVN_ERR_LAUNCH;
+  }
+  auto signal = [&](int e, hipStream_t from) {
+    if (fork) (void)hipEventRecord(side->ev[e], from);
+  };
+  auto await = [&](int e, hipStream_t on) {
+    if (fork) (void)hipStreamWaitEvent(on, side->ev[e], 0);
+  };
   for (int l = g.L - 1; l >= 0; --l) {
     const int d = dilation_of(dims, l);
     const int t_lo = A_lo[l + 1];
@@ -855,32 +910,41 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     Act sg = act_view(fwd->sg + (size_t)l * g.act, batch, C, g.Tp);
     Act xin = act_view(fwd->acts + (size_t)l * g.act, batch, C, g.Tp);
     Act dxo = act_view(dxo_p, batch, C, g.Tp);
+    if (l < g.L - 1) {  // the side stream's work on the previous layer read dxo's twin and dfg
+      await(2, s);
+      await(3, s);
+    }
+    await(0, s2);
     WgRsOp wr;
     wr.t_begin = t_lo; wr.t_end = T; wr.C = C; wr.Kc = Kc; wr.t_skip0 = t_skip0; wr.t_base = g.t_base;
     wr.dxo = dxo; wr.dskip = dskip; wr.th = th; wr.sg = sg;
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
     if (bias_scratch2)
-      launch_wgrad2<1>(wr, C + Kc, C, batch, bias_scratch2, slab, slab_floats, s);
+      launch_wgrad2<1>(wr, C + Kc, C, batch, bias_scratch2, slab, slab_floats, s2);
     else
-      launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s);
+      launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s2);
+    signal(2, s2);
     DzOp dz;
     dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
     dz.t_base = g.t_base;
     dz.wr = p->residual_w[l]; dz.ws = p->skip_w[l];
     dz.dxo = dxo; dz.dskip = dskip; dz.th = th; dz.sg = sg; dz.dfg = dfg;
     launch_gemm_staged(dz, C, batch, s);
+    signal(1, s);
+    await(1, s2);
     auto run_wf = [&](auto wf) {
       wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
       wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
       wf.dwcf = has_ctx ? gr->ctx_filter_w[l] : nullptr; wf.dwcg = has_ctx ? gr->ctx_gate_w[l] : nullptr;
       wf.dbcf = has_ctx ? gr->ctx_filter_b[l] : nullptr; wf.dbcg = has_ctx ? gr->ctx_gate_b[l] : nullptr;
       if (!has_ctx)
-        launch_wgrad2<2>(wf, 2 * C, 2 * C, batch, nullptr, slab, slab_floats, s);
+        launch_wgrad2<2>(wf, 2 * C, 2 * C, batch, nullptr, slab, slab_floats, s2);
       else
-        launch_wgrad(wf, 2 * C, 3 * C, batch, ctx_bias_scratch, s);
+        launch_wgrad(wf, 2 * C, 3 * C, batch, ctx_bias_scratch, s2);
     };
     if (has_ctx) run_wf(WgFgOpT<true>()); else run_wf(WgFgOpT<false>());
+    signal(3, s2);
     if (has_ctx) {
       DctxOp dc;
       dc.K = 2 * C; dc.t_begin = t_lo; dc.t_end = T; dc.C = C;
@@ -892,9 +956,12 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];
     dx.dxo = dxo; dx.dfg = dfg; dx.dxi = act_view(cur, batch, C, g.Tp);
     launch_gemm_staged(dx, C, batch, s);
+    signal(0, s);
     dxo_p = cur;
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
+  await(2, s);  // join: everything the side stream did is ordered before what follows on s
+  await(3, s);
   if (fwd->dense_audio) {
     WgCausalOp wc;
     wc.t_begin = 0; wc.t_end = T; wc.C = C; wc.Q = Q; wc.dx0 = act_view(dxo_p, batch, C, g.Tp);
