@@ -112,7 +112,7 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
     }
 
 
-def train_leg(dev, world, rank, steps=3, warmup=1, batch=16, t_len=16000):
+def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
     """Secondary metric M2 (BASELINE.json): train-step tokens/sec on config 2 --
     forward (probabilities), cross_entropy on them (Q2), backward through the HIP
     kernels, one flat gradient all-reduce when world > 1, AdamW.  Token = one
@@ -146,12 +146,17 @@ def train_leg(dev, world, rank, steps=3, warmup=1, batch=16, t_len=16000):
         import torch.distributed as dist
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
+    for i in range(steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    log(f"rank {rank}: train steps (ms) "
+        f"{[round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(steps)]}")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -229,7 +229,10 @@ typedef struct mvn_bwd_buffers {
 } mvn_bwd_buffers;
 
 /* dout: gradient w.r.t. mvn_forward's `out` (same shape); `out` itself is needed
- * when normalize != 0 (softmax backward).  Requires the forward ran with save. */
+ * when normalize != 0 (softmax backward).  Requires the forward ran with save.
+ * Part of the work is enqueued on a stream the library owns (one per device) and joined
+ * back into `stream` with events before the call returns: to the caller it is ordinary
+ * stream-ordered work.  da1 / dlogit / dfg double as scratch of the weight gradients. */
 int mvn_backward(const mvn_dims *dims, const mvn_params *params, const mvn_param_grads *grads,
                  const int32_t *index, int index_stride, int batch, int t_len,
                  const mvn_fwd_buffers *fwd, const mvn_bwd_buffers *bwd, const float *out,

@@ -209,3 +209,29 @@ def test_config5_pipe_matches_generic_over_a_long_run():
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_GENERIC])
     assert len(torch.unique(runs[N.GEN_PIPE][:, rf:])) > 4
+
+
+def test_integration_stub_runs():
+    """The ctypes stub INTEGRATION.md hands to a movenet maintainer, executed as written
+    (against this build's WaveNet, which has the reference's attribute names): its greedy
+    output equals WaveNet.generate's."""
+    import os
+    import re
+    from movenet_amd.utils.weights import make_state_dict
+    from movenet_amd.wavenet import WaveNet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\nimport ctypes as C, torch\n(.*?)```", text, re.S).group(0)
+    code = code[len("```python\n"):-3].replace(
+        'C.CDLL("libmovenet_hip.so")', f'C.CDLL({os.path.join(root, "movenet_amd", "lib", "libmovenet_hip.so")!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    cfg = dict(layer_size=3, stack_size=2, input_channels=64, residual_channels=16, skip_channels=16)
+    model = WaveNet(**cfg)
+    model.load_state_dict(make_state_dict(**cfg, seed=3, gain=2.0, head_gain=6.0), strict=False)
+    model.to(DEV)
+    rf = model.receptive_fields
+    prompt = one_hot(synthetic_indices(2, rf, 64, 11), 64).to(DEV)
+    want = model.generate(prompt, n_samples=rf + 20, temperature=0.0)
+    got = ns["fast_generate"](model, prompt, rf + 20, temperature=0.0)
+    assert torch.equal(got, want)
