@@ -204,13 +204,8 @@ __device__ __forceinline__ float dotn(const v2f (&w)[2 * N4], const f4 (&x)[N4])
 }
 template <int N4>
 __device__ __forceinline__ void ldsn(f4 (&x)[N4], const float *p) {
-#if MVN_EXP == 2  // experiment: 1/N4 of the LDS traffic
-#pragma unroll
-  for (int i = 0; i < N4; ++i) x[i] = ((const f4 *)p)[0];
-#else
 #pragma unroll
   for (int i = 0; i < N4; ++i) x[i] = ((const f4 *)p)[i];
-#endif
 }
 // N4 float4 of a [..][stride] block -> 2*N4 float2 registers
 template <int N4>

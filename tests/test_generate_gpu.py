@@ -160,6 +160,27 @@ def test_config2_full_size_properties():
     assert np.array_equal(ridx, runs[N.GEN_STREAM][sub].cpu().numpy())
 
 
+def test_config2_pipe_at_full_occupancy():
+    """24 sequences = 3 nine-stage pipelines in each of the 8 XCDs (the most that are
+    co-resident): PIPE still equals STREAM, and one more sequence is refused for PIPE."""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=5, gain=2.0, head_gain=6.0)
+    rf, B, n_new = 3072, 24, 40
+    pidx = synthetic_indices(B, rf, 256, 77).to(DEV)
+    runs = {}
+    for variant in (N.GEN_STREAM, N.GEN_PIPE):
+        g = _gen(cfg, sd, B, rf + n_new, variant=variant)
+        g.prime(pidx)
+        g.advance(n_new)
+        g.check_errors()
+        runs[variant] = g.samples.clone()
+    assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
+    assert _gen(cfg, sd, 25, rf + 1).variant == N.GEN_STREAM  # AUTO falls back
+    with pytest.raises(Exception):
+        _gen(cfg, sd, 25, rf + 1, variant=N.GEN_PIPE)
+
+
 def test_bad_input_raises():
     from movenet_amd.wavenet import WaveNet
     model = WaveNet(2, 2, 64, 16, 16).to(DEV)
