@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
   const int srow = tid >> 4, st = 4 * (tid & 15);
   f4 areg[8], xreg[4 * NB];
   float bsum[8];
+  unsigned azero = 0;  // A rows of the staged tile that are zero (see gload)
 #pragma unroll
   for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
   auto gload = [&](int t0) {
@@ -396,11 +397,18 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
       xp[p] = op.x_ptr(b, nblk * 64 * NB + 16 * p + srow_q);
       xq[p] = Op::X_PRODUCT ? op.x_ptr2(b, nblk * 64 * NB + 16 * p + srow_q) : nullptr;
     }
+    // A rows whose range misses the tile altogether (the skip gradient before t_skip0, the
+    // absent dxo rows of the last layer) still take the unmasked path: they load a row that
+    // IS valid here and are zeroed at the LDS store (azero, bit p)
     bool inter = t0 + W2_T <= te;
+    unsigned zero_bits = 0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int m = mblk * 128 + 16 * p + srow;
-      inter = inter && t0 >= op.a_lo(m) && t0 + W2_T <= op.a_hi(m);
+      const int lo = op.a_lo(m), hi = op.a_hi(m);
+      const bool full = t0 >= lo && t0 + W2_T <= hi, none = t0 + W2_T <= lo || t0 >= hi;
+      inter = inter && (full || none);
+      if (none) zero_bits |= 1u << p;
     }
 #pragma unroll
     for (int p = 0; p < 4 * NB; ++p) {
@@ -408,9 +416,13 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
       inter = inter && t0 >= op.x_lo(n) && t0 + W2_T <= op.x_hi(n);
     }
     const int t = t0 + st;
+    azero = 0;
     if (__all(inter)) {
+      azero = zero_bits;
+      // (xp[0] is valid over this tile -- every X row is; its index 0 need not be readable,
+      // so the masked path below keeps the row's own pointer)
 #pragma unroll
-      for (int p = 0; p < 8; ++p) areg[p] = ldg4(ap[p] + t);
+      for (int p = 0; p < 8; ++p) areg[p] = ldg4((((zero_bits >> p) & 1u) ? xp[0] : ap[p]) + t);
 #pragma unroll
       for (int p = 0; p < 4 * NB; ++p) {
         xreg[p] = ldg4(xp[p] + t);
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
   auto lstore = [&]() {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
+      if ((azero >> p) & 1u) areg[p] = f4{0.f, 0.f, 0.f, 0.f};
       *(f4 *)&As[16 * p + srow][st] = areg[p];
       if (Op::HAS_BIAS)  // bias gradient = row sums of A
         bsum[p] += (areg[p].x + areg[p].y) + (areg[p].z + areg[p].w);

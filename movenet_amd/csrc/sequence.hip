@@ -18,6 +18,7 @@
 // Activations use an ABSOLUTE time axis (see movenet_hip.h): tensor (B, ch, Tp),
 // column t = input time t, layer l's input valid for t >= A_l.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -889,7 +890,13 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   //   ev[1]: dfg of this layer ready (s -> s2)
   //   ev[2], ev[3]: WgRs / WgFg done (s2 -> s: the buffers they read may be overwritten)
   SideStream *side = nullptr;
-  const bool fork = !has_ctx && bias_scratch2;
+  // MOVENET_HIP_NO_SIDE_STREAM=1 keeps everything on the caller's stream (profiling: kernel
+  // durations are only comparable when the kernels do not share the machine)
+  static const bool no_side = [] {
+    const char *e = getenv("MOVENET_HIP_NO_SIDE_STREAM");
+    return e && e[0] == '1';
+  }();
+  const bool fork = !has_ctx && bias_scratch2 && !no_side;
   hipStream_t s2 = s;
   if (fork) {
     rc = side_stream(&side);
