@@ -117,7 +117,7 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
     forward (probabilities), cross_entropy on them (Q2), backward through the HIP
     kernels, one flat gradient all-reduce when world > 1, AdamW.  Token = one
     (sequence, time) position with a target: B * (T - RF)."""
-    import torch.nn.functional as F
+    from movenet_amd.ops import cross_entropy_on_probs
     from movenet_amd.parallel import FlatGradSync
     from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices
     from movenet_amd.wavenet import WaveNet
@@ -133,7 +133,7 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = F.cross_entropy(model(audio), target)
+        loss, _ = cross_entropy_on_probs(model(audio), target)  # the trainer's fused loss + accuracy
         loss.backward()
         sync.sync_gradients()
         opt.step()

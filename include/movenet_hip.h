@@ -283,6 +283,23 @@ int mvn_onehot_to_index(const float *onehot, int32_t *index, int batch, int clas
 int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, int batch,
                         int classes, int t_len, void *stream);
 
+/* The trainer's loss and accuracy on the model output (row F3 of SURVEY.md section 8;
+ * movenet/pytorch_lightning_trainer.py:64-66): cross_entropy applied to PROBABILITIES
+ * (SURVEY Q2), i.e.  loss = mean over (b,s) of  logsumexp_q(probs[b,:,s]) - probs[b,target,s],
+ * accuracy = mean of [first argmax_q probs[b,:,s] == target[b,s]].
+ *   probs (B, Q, S) fp32, target (B, S) int64 class indices.
+ * forward: per-workgroup partial sums, loss_part / correct_part have mvn_ce_parts(B,S)
+ *   entries each (summed by the caller in a fixed order: deterministic).
+ * backward: dprobs = scale * upstream * (softmax_q(probs) - onehot(target)); scale = 1/(B*S) for
+ *   the mean, `upstream` = device pointer to the scalar gradient of the loss (NULL: 1), read
+ *   by the kernel so that the host never has to synchronise for it. */
+int mvn_ce_parts(int batch, int s_len);
+int mvn_ce_on_probs_forward(const float *probs, const long long *target, int batch, int classes,
+                            int s_len, float *loss_part, int32_t *correct_part, void *stream);
+int mvn_ce_on_probs_backward(const float *probs, const long long *target, int batch, int classes,
+                             int s_len, float scale, const float *upstream, float *dprobs,
+                             void *stream);
+
 /* mu-law companding either side of the model (movenet/dataset.py:278-289 encode ->
  * one-hot; movenet/callbacks.py:66-76 argmax -> decode).  The reference calls torchaudio,
  * which is absent offline and pinned by no fixture: formula of RESEARCH.md:156-163,

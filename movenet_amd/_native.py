@@ -123,6 +123,11 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p]),
     "mvn_gen_prime_from_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(FwdBuffers), C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p]),
+    "mvn_ce_parts": (C.c_int, [C.c_int, C.c_int]),
+    "mvn_ce_on_probs_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "mvn_ce_on_probs_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvn_mu_law_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "mvn_mu_law_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "mvn_onehot_to_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

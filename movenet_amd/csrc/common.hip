@@ -86,9 +86,105 @@ __global__ void mu_law_decode_kernel(const int32_t *__restrict__ q, float *__res
   x[i] = copysignf((expf(fabsf(y) * log1pf(mu)) - 1.0f) / mu, y);
 }
 
+// ---- F3: cross_entropy on probabilities + accuracy (pytorch_lightning_trainer.py:64-66) ----
+// one thread per (b, s) column, lanes walk s (coalesced), two passes over the Q rows
+__global__ __launch_bounds__(256) void ce_probs_fwd_kernel(const float *__restrict__ p,
+                                                           const long long *__restrict__ target, int Q,
+                                                           int S, float *__restrict__ loss_part,
+                                                           int32_t *__restrict__ correct_part) {
+  const int b = blockIdx.y, sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  float loss = 0.f;
+  int ok = 0;
+  if (sidx < S) {
+    const float *col = p + (size_t)b * Q * S + sidx;
+    float m = -INFINITY;
+    int arg = 0;
+    for (int q = 0; q < Q; ++q) {
+      const float v = col[(size_t)q * S];
+      if (v > m) {  // strict: first maximum, like torch.argmax
+        m = v;
+        arg = q;
+      }
+    }
+    float sum = 0.f;
+    for (int q = 0; q < Q; ++q) sum += expf(col[(size_t)q * S] - m);
+    const long long tg = target[(size_t)b * S + sidx];
+    const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
+    loss = (m + logf(sum)) - col[(size_t)tq * S];
+    ok = arg == tq;
+  }
+  __shared__ float ls[4];
+  __shared__ int cs[4];
+  loss = wave_sum(loss);
+  float okf = wave_sum((float)ok);  // <= 64: exact
+  if ((threadIdx.x & 63) == 0) {
+    ls[threadIdx.x >> 6] = loss;
+    cs[threadIdx.x >> 6] = (int)okf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int part = blockIdx.y * gridDim.x + blockIdx.x;
+    loss_part[part] = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    correct_part[part] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_probs_bwd_kernel(const float *__restrict__ p,
+                                                           const long long *__restrict__ target, int Q,
+                                                           int S, float scale,
+                                                           const float *__restrict__ upstream,
+                                                           float *__restrict__ dp) {
+  const int b = blockIdx.y, sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= S) return;
+  if (upstream) scale *= *upstream;
+  const float *col = p + (size_t)b * Q * S + sidx;
+  float *dcol = dp + (size_t)b * Q * S + sidx;
+  float m = -INFINITY;
+  for (int q = 0; q < Q; ++q) m = fmaxf(m, col[(size_t)q * S]);
+  float sum = 0.f;
+  for (int q = 0; q < Q; ++q) sum += expf(col[(size_t)q * S] - m);
+  const float inv = 1.0f / sum;
+  const long long tg = target[(size_t)b * S + sidx];
+  const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
+  for (int q = 0; q < Q; ++q) {
+    const float sm = expf(col[(size_t)q * S] - m) * inv;
+    dcol[(size_t)q * S] = scale * (sm - (q == tq ? 1.0f : 0.0f));
+  }
+}
+
 }  // namespace mvn
 
 extern "C" {
+
+int mvn_ce_parts(int batch, int s_len) {
+  if (batch < 0 || s_len < 0) return 0;
+  return batch * ((s_len + 255) / 256);
+}
+
+int mvn_ce_on_probs_forward(const float *probs, const long long *target, int batch, int classes,
+                            int s_len, float *loss_part, int32_t *correct_part, void *stream) {
+  if (!probs || !target || !loss_part || !correct_part || batch < 0 || classes < 2 || s_len < 0) {
+    mvn::set_error("mvn_ce_on_probs_forward: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0 || s_len == 0) return MVN_OK;
+  hipLaunchKernelGGL(mvn::ce_probs_fwd_kernel, dim3((s_len + 255) / 256, batch), dim3(256), 0,
+                     (hipStream_t)stream, probs, target, classes, s_len, loss_part, correct_part);
+  return mvn::check_hip(hipGetLastError(), "ce_on_probs_forward");
+}
+
+int mvn_ce_on_probs_backward(const float *probs, const long long *target, int batch, int classes,
+                             int s_len, float scale, const float *upstream, float *dprobs,
+                             void *stream) {
+  if (!probs || !target || !dprobs || batch < 0 || classes < 2 || s_len < 0) {
+    mvn::set_error("mvn_ce_on_probs_backward: bad argument");
+    return MVN_ERR_BAD_ARG;
+  }
+  if (batch == 0 || s_len == 0) return MVN_OK;
+  hipLaunchKernelGGL(mvn::ce_probs_bwd_kernel, dim3((s_len + 255) / 256, batch), dim3(256), 0,
+                     (hipStream_t)stream, probs, target, classes, s_len, scale, upstream, dprobs);
+  return mvn::check_hip(hipGetLastError(), "ce_on_probs_backward");
+}
 
 int mvn_mu_law_encode(const float *x, int32_t *index, size_t n, int classes, void *stream) {
   if (!x || !index || classes < 2) {

@@ -271,3 +271,51 @@ def mu_law_decode(index: torch.Tensor, quantization_channels: int) -> torch.Tens
                                           quantization_channels, _stream_ptr(index.device)),
                 "mvn_mu_law_decode")
     return out
+
+
+class _CrossEntropyOnProbs(torch.autograd.Function):
+    """loss, accuracy of the trainer (row F3): mvn_ce_on_probs_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx_, probs, target):
+        _require_gpu(probs, "probs")
+        if probs.dim() != 3 or target.shape != (probs.shape[0], probs.shape[2]):
+            raise ValueError(f"probs (B,Q,S) / target (B,S) expected, got {tuple(probs.shape)} / "
+                             f"{tuple(target.shape)}")
+        p = probs.detach().to(torch.float32).contiguous()
+        tg = target.detach().to(device=p.device, dtype=torch.int64).contiguous()
+        B, Q, S = p.shape
+        lib = N.lib()
+        with torch.cuda.device(p.device):
+            parts = lib.mvn_ce_parts(B, S)
+            loss_part = torch.zeros(max(parts, 1), dtype=torch.float32, device=p.device)
+            ok_part = torch.zeros(max(parts, 1), dtype=torch.int32, device=p.device)
+            N.check(lib.mvn_ce_on_probs_forward(p.data_ptr(), tg.data_ptr(), B, Q, S, loss_part.data_ptr(),
+                                                ok_part.data_ptr(), _stream_ptr(p.device)),
+                    "mvn_ce_on_probs_forward")
+        n = max(B * S, 1)
+        ctx_.save_for_backward(p, tg)
+        ctx_.in_dtype = probs.dtype
+        loss = loss_part.sum() / n
+        acc = ok_part.sum().to(torch.float32) / n
+        ctx_.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx_, dloss, _dacc):
+        p, tg = ctx_.saved_tensors
+        B, Q, S = p.shape
+        dp = torch.empty_like(p)
+        up = dloss.detach().to(device=p.device, dtype=torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(p.device):
+            N.check(N.lib().mvn_ce_on_probs_backward(p.data_ptr(), tg.data_ptr(), B, Q, S,
+                                                     1.0 / max(B * S, 1), up.data_ptr(), dp.data_ptr(),
+                                                     _stream_ptr(p.device)), "mvn_ce_on_probs_backward")
+        return dp.to(ctx_.in_dtype), None
+
+
+def cross_entropy_on_probs(probs: torch.Tensor, target: torch.Tensor):
+    """(loss, accuracy) of movenet/pytorch_lightning_trainer.py:64-66 in two kernels:
+    ``F.cross_entropy(probs, target)`` -- a log-softmax applied to what already are
+    probabilities -- and ``(probs.argmax(1) == target).float().mean()``."""
+    return _CrossEntropyOnProbs.apply(probs, target)

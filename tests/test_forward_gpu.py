@@ -78,13 +78,17 @@ def test_g4_trainer_arithmetic_and_gradients(golden, name):
     Q = cfg["input_channels"]
     x = one_hot(synthetic_indices(int(fx["B"]), int(fx["T"]), Q, int(fx["idx_seed"])), Q).to(DEV)
     m = _model(cfg, sd).train()
+    from movenet_amd.ops import cross_entropy_on_probs
     out = m(x)
     target = x[:, :, m.receptive_fields:].argmax(1)
-    loss = F.cross_entropy(out, target)
-    acc = (out.argmax(1) == target).float().mean()
+    loss, acc = cross_entropy_on_probs(out, target)  # the fused loss + accuracy kernels (row F3)
     loss.backward()
     assert abs(loss.item() - float(fx["loss"])) < 2e-6
     assert abs(acc.item() - float(fx["acc"])) < 1e-6
+    # ... and they are what torch computes from the same probabilities
+    with torch.no_grad():
+        assert abs(F.cross_entropy(out, target).item() - loss.item()) < 1e-6
+        assert (out.argmax(1) == target).float().mean().item() == acc.item()
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     names = [str(n) for n in fx["grad_names"]]
     assert sorted(grads) == names  # same set of parameters receives a gradient
@@ -199,3 +203,24 @@ def test_config2_full_size_training_step_properties():
     assert rel_err(g2.cpu(), (2.5 * g1).cpu()) < 1e-4        # atomics: last bits may differ
     g0, = torch.autograd.grad((out * 0).sum(), m.causal_conv.conv.weight)
     assert torch.count_nonzero(g0).item() == 0
+
+
+def test_cross_entropy_on_probs_matches_torch_autograd():
+    """Row F3 on its own: loss, accuracy and d loss / d probs against torch ops, with a
+    non-unit upstream gradient, ragged column count and ties in the argmax."""
+    from movenet_amd.ops import cross_entropy_on_probs
+    torch.manual_seed(3)
+    B, Q, S = 3, 37, 300  # S not a multiple of the 256-column workgroups
+    probs = torch.softmax(torch.randn(B, Q, S, device=DEV) * 3, 1)
+    probs[0, 5, 7] = probs[0, 9, 7] = probs[0, :, 7].max() + 0.1  # tie: first maximum wins
+    target = torch.randint(0, Q, (B, S), device=DEV)
+    a = probs.clone().requires_grad_(True)
+    b = probs.clone().requires_grad_(True)
+    loss, acc = cross_entropy_on_probs(a, target)
+    (loss * 2.5).backward()
+    ref = F.cross_entropy(b, target)
+    (ref * 2.5).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert acc.item() == (b.argmax(1) == target).float().mean().item()
+    assert rel_err(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6
+    assert not acc.requires_grad
