@@ -159,6 +159,9 @@ class Trainer:
         self.limit = limit_train_batches
         self.device = device
         self.checkpointing = enable_checkpointing
+        self.callbacks = list(callbacks or [])
+        self.current_epoch = 0
+        self.rank = 0
         self.history = []      # one dict per optimizer step
         self.global_step = 0
 
@@ -167,6 +170,7 @@ class Trainer:
                                                    if torch.cuda.is_available() else "gloo",
                                                    model.config.dist_port)
         model.rank, model.world_size = rank, world
+        self.rank = rank
         dev = torch.device(self.device) if self.device else torch.device("cuda", local_rank)
         if dev.type != "cuda":
             raise RuntimeError("movenet_amd trains on MI355X devices only (no CPU path)")
@@ -181,7 +185,7 @@ class Trainer:
             self.root.mkdir(parents=True, exist_ok=True)
             log_f = open(self.root / "metrics.jsonl", "a")
         for epoch in range(self.max_epochs):
-            model.current_epoch = epoch
+            model.current_epoch = self.current_epoch = epoch
             model.train()
             loader = model.train_dataloader()
             loader.set_epoch(epoch)
@@ -193,6 +197,8 @@ class Trainer:
                     break
                 out = model.training_step(batch, batch_idx)
                 (out["loss"] / self.accum).backward()
+                for cb in self.callbacks:
+                    cb.on_train_batch_end(self, model, out, batch, batch_idx)
                 if (batch_idx + 1) % self.accum == 0 or batch_idx + 1 == n_batches:
                     sync.sync_gradients()
                     rec = {"epoch": epoch, "step": self.global_step, **model.logged}
@@ -221,7 +227,9 @@ class Trainer:
                 for batch_idx, batch in enumerate(model.val_dataloader()):
                     if self.limit is not None and batch_idx >= self.limit:
                         break
-                    model.validation_step(batch, batch_idx)
+                    out = model.validation_step(batch, batch_idx)
+                    for cb in self.callbacks:
+                        cb.on_validation_batch_end(self, model, out, batch, batch_idx, 0)
             if rank == 0:
                 print(json.dumps({"epoch": epoch, "epoch_seconds": epoch_s,
                                   **{k: v for k, v in model.logged.items() if k.startswith("val")}}),
@@ -246,11 +254,17 @@ def train_model(dataset: str, config: TrainingConfig, logger_name: Optional[str]
         raise NotImplementedError("wandb logging is a SaaS integration and out of scope "
                                   "(SURVEY.md section 2); metrics go to <model_output_path>/metrics.jsonl")
     print("Using logger: None")
+    callbacks = []
+    if config.log_samples_every:
+        # the reference attaches this callback only under wandb (:223-229); without wandb the
+        # decoded samples go to <model_output_path>/samples/ as .wav files
+        from .callbacks import LogSamplesCallback
+        callbacks.append(LogSamplesCallback(log_every_n_epochs=config.log_samples_every, log_video=log_video))
     trainer = Trainer(
         max_epochs=config.n_epochs, default_root_dir=config.model_output_path,
         gradient_clip_val=config.gradient_clipping,
         accumulate_grad_batches=config.accumulation_steps, logger=None, log_every_n_steps=1,
-        num_sanity_val_steps=0, callbacks=[], track_grad_norm=2,
+        num_sanity_val_steps=0, callbacks=callbacks, track_grad_norm=2,
         limit_train_batches=(limit_train_batches if limit_train_batches is not None
                              else config.n_steps_per_epoch))
     trainer.fit(model=model)

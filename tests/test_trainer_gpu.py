@@ -97,3 +97,40 @@ def test_video_conditioned_training_runs(tmp_path, monkeypatch):
     assert "video_conv.weight" in changed and "video_transpose.2.bias" in changed
     assert "residual_conv_stack.conv_layers.0.context_conv_gate.weight" in changed
     assert "residual_conv_stack.conv_layers.3.conv_residual.weight" not in changed
+
+
+def test_sample_logging_writes_decoded_wavs(tmp_path):
+    """Row F4: every log_samples_every epochs the predictions and the free-running
+    generation are mu-law decoded on the GPU and written as 16 kHz wav files plus an
+    index, through the same callback hooks the reference uses under wandb."""
+    import json
+    import wave
+    from movenet_amd.ops import mu_law_decode
+    from movenet_amd.pytorch_lightning_trainer import train_model
+    mc = ModelConfig(layer_size=2, stack_size=2, input_channels=64, residual_channels=16,
+                     skip_channels=16)
+    cfg = TrainingConfig(model_config=mc, batch_size=2, val_batch_size=2, n_epochs=2,
+                         use_video=False, optimizer="AdamW", learning_rate=1e-3,
+                         scheduler="OneCycleLR", max_learning_rate=3e-3, accumulation_steps=1,
+                         model_output_path=tmp_path, log_samples_every=2, generate_n_samples=40,
+                         generate_temperature=0.0)
+    train_model("synthetic://clips=4,frames=60,seed=2", cfg, limit_train_batches=1)
+    root = tmp_path / "samples"
+    rows = [json.loads(l) for l in open(root / "index.jsonl")]
+    # only epoch index 1 is logged ((epoch + 1) % 2 == 0): 1 train batch + the validation batches
+    assert rows and {r["epoch"] for r in rows} == {1} and {r["split"] for r in rows} == {"train", "validation"}
+    r0 = rows[0]
+    for key, n in (("origin_audio", 60), ("pred_audio", 60 - 8), ("gen_audio", 40)):
+        with wave.open(str(root / r0[key])) as w:
+            assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (16000, 1, 2)
+            assert w.getnframes() == n, key  # RF = 8: 60 - 8 + 1 predictions, the last removed
+    # the generated clip starts with the (decoded) prompt
+    with wave.open(str(root / r0["gen_audio"])) as w:
+        gen = np.frombuffer(w.readframes(40), dtype="<i2")
+    with wave.open(str(root / r0["origin_audio"])) as w:
+        org = np.frombuffer(w.readframes(60), dtype="<i2")
+    assert np.array_equal(gen[:8], org[:8])
+    # wav samples are the decoded class values
+    vals = (mu_law_decode(torch.arange(64, dtype=torch.int32, device="cuda:0"), 64).cpu().numpy()
+            .clip(-1, 1) * 32767).round().astype(np.int16)
+    assert set(org.tolist()) <= set(vals.tolist())
