@@ -67,9 +67,9 @@ struct FgOpT {
       fb = bcf[c];
       gb = bcg[c];
     }
-    const f4 tv = f4{tanhf(f.x + fb), tanhf(f.y + fb), tanhf(f.z + fb), tanhf(f.w + fb)};
-    const f4 sv = f4{1.0f / (1.0f + expf(-(g.x + gb))), 1.0f / (1.0f + expf(-(g.y + gb))),
-                     1.0f / (1.0f + expf(-(g.z + gb))), 1.0f / (1.0f + expf(-(g.w + gb)))};
+    const f4 tv = f4{tanh_fast(f.x + fb), tanh_fast(f.y + fb), tanh_fast(f.z + fb), tanh_fast(f.w + fb)};
+    const f4 sv = f4{sigmoid_fast(g.x + gb), sigmoid_fast(g.y + gb), sigmoid_fast(g.z + gb),
+                     sigmoid_fast(g.w + gb)};
     const f4 zv = f4{tv.x * sv.x, tv.y * sv.y, tv.z * sv.z, tv.w * sv.w};
     float *zp = z.at(b, c, t);
     if (cols_full(t, t_begin, t_end)) {
