@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
   const int srow = tid >> 4, st = 4 * (tid & 15);
   f4 areg[8], xreg[4 * NB];
   float bsum[8];
-  unsigned azero = 0;  // A rows of the staged tile that are zero (see gload)
+  unsigned azero = 0, xzero = 0;  // rows of the staged tile that are zero (see gload)
 #pragma unroll
   for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
   auto gload = [&](int t0) {
@@ -410,22 +410,32 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
       inter = inter && (full || none);
       if (none) zero_bits |= 1u << p;
     }
+    // Op::X_ABSENT_ROWS: X rows may be missing too (a half-used block: 3C rows of the
+    // conditioned filter/gate gradient in two 128-row blocks); they borrow ap[0], which such
+    // an op guarantees to be a real row, and are zeroed at the LDS store (xzero)
+    unsigned xzero_bits = 0;
 #pragma unroll
     for (int p = 0; p < 4 * NB; ++p) {
       const int n = nblk * 64 * NB + 16 * p + srow;
-      inter = inter && t0 >= op.x_lo(n) && t0 + W2_T <= op.x_hi(n);
+      const int lo = op.x_lo(n), hi = op.x_hi(n);
+      const bool full = t0 >= lo && t0 + W2_T <= hi;
+      const bool none = Op::X_ABSENT_ROWS && (t0 + W2_T <= lo || t0 >= hi);
+      inter = inter && (full || none);
+      if (none) xzero_bits |= 1u << p;
     }
     const int t = t0 + st;
     azero = 0;
+    xzero = 0;
     if (__all(inter)) {
       azero = zero_bits;
+      xzero = xzero_bits;
       // (xp[0] is valid over this tile -- every X row is; its index 0 need not be readable,
       // so the masked path below keeps the row's own pointer)
 #pragma unroll
       for (int p = 0; p < 8; ++p) areg[p] = ldg4((((zero_bits >> p) & 1u) ? xp[0] : ap[p]) + t);
 #pragma unroll
       for (int p = 0; p < 4 * NB; ++p) {
-        xreg[p] = ldg4(xp[p] + t);
+        xreg[p] = ldg4(((Op::X_ABSENT_ROWS && ((xzero_bits >> p) & 1u)) ? ap[0] : xp[p]) + t);
         if (Op::X_PRODUCT) {
           const f4 v = ldg4(xq[p] + t);
           xreg[p] = f4{xreg[p].x * v.x, xreg[p].y * v.y, xreg[p].z * v.z, xreg[p].w * v.w};
@@ -458,7 +468,10 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
         bsum[p] += (areg[p].x + areg[p].y) + (areg[p].z + areg[p].w);
     }
 #pragma unroll
-    for (int p = 0; p < 4 * NB; ++p) *(f4 *)&Xs[16 * p + srow][st] = xreg[p];
+    for (int p = 0; p < 4 * NB; ++p) {
+      if (Op::X_ABSENT_ROWS && ((xzero >> p) & 1u)) xreg[p] = f4{0.f, 0.f, 0.f, 0.f};
+      *(f4 *)&Xs[16 * p + srow][st] = xreg[p];
+    }
   };
 
   gload(tb);

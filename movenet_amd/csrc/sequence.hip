@@ -378,6 +378,7 @@ struct WgFgOpT {
   // row descriptors for wgrad2 (gemm_family.h): p[t] = value at absolute time t
   static constexpr bool X_PRODUCT = false;
   static constexpr bool HAS_BIAS = HAS_CTX;  // only the context convs carry biases
+  static constexpr bool X_ABSENT_ROWS = HAS_CTX;  // 3C rows fill one and a half 128-row blocks
   __device__ __forceinline__ const float *a_ptr(int b, int m) const { return dfg.at(b, min(m, 2 * C - 1), 0); }
   __device__ __forceinline__ int a_lo(int m) const { return m < 2 * C ? t_begin : 0; }
   __device__ __forceinline__ int a_hi(int m) const { return m < 2 * C ? t_end : 0; }
@@ -460,6 +461,7 @@ struct WgRsOp {
   // row descriptors for wgrad2: dskip's column axis is t - t_base, valid from t_skip0
   static constexpr bool X_PRODUCT = true;  // z = th * sg
   static constexpr bool HAS_BIAS = true;
+  static constexpr bool X_ABSENT_ROWS = false;
   __device__ __forceinline__ const float *a_ptr(int b, int m) const {
     if (m < C) return dxo.p ? dxo.at(b, m, 0) : dskip.at(b, 0, 0);  // absent row: p[0] must exist
     if (m < C + Kc) return dskip.at(b, m - C, 0) - t_base;
@@ -885,7 +887,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   float *dxo_p = nullptr;  // gradient w.r.t. the layer's residual output
   float *cur = bwd->dx_a, *nxt = bwd->dx_b;
   Act dfg = act_view(bwd->dfg, batch, 2 * C, g.Tp);
-  // Two streams (audio only): per layer  WgRs || Dz  then  WgFg || Dx.
+  // Two streams: per layer  WgRs || Dz  then  WgFg || (Dctx,) Dx.
   //   ev[0]: dx of the previous layer / the head's dskip ready (s -> s2)
   //   ev[1]: dfg of this layer ready (s -> s2)
   //   ev[2], ev[3]: WgRs / WgFg done (s2 -> s: the buffers they read may be overwritten)
@@ -896,7 +898,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     const char *e = getenv("MOVENET_HIP_NO_SIDE_STREAM");
     return e && e[0] == '1';
   }();
-  const bool fork = !has_ctx && bias_scratch2 && !no_side;
+  const bool fork = bias_scratch2 && !no_side;
   hipStream_t s2 = s;
   if (fork) {
     rc = side_stream(&side);
@@ -947,6 +949,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       wf.dbcf = has_ctx ? gr->ctx_filter_b[l] : nullptr; wf.dbcg = has_ctx ? gr->ctx_gate_b[l] : nullptr;
       if (!has_ctx)
         launch_wgrad2<2>(wf, 2 * C, 2 * C, batch, nullptr, slab, slab_floats, s2);
+      else if (bias_scratch2)  // (shares the bias scratch with WgRs: same stream, one after the other)
+        launch_wgrad2<2>(wf, 2 * C, 3 * C, batch, bias_scratch2, slab, slab_floats, s2);
       else
         launch_wgrad(wf, 2 * C, 3 * C, batch, ctx_bias_scratch, s2);
     };
