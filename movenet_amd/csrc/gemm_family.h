@@ -470,7 +470,8 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
 #pragma unroll
     for (int p = 0; p < 4 * NB; ++p) {
       if (Op::X_ABSENT_ROWS && ((xzero >> p) & 1u)) xreg[p] = f4{0.f, 0.f, 0.f, 0.f};
-      *(f4 *)&Xs[16 * p + srow][st] = xreg[p];
+      const f4 v = xreg[p];  // Op::xmap: element-wise input transform (leaky-ReLU of the head)
+      *(f4 *)&Xs[16 * p + srow][st] = f4{op.xmap(v.x), op.xmap(v.y), op.xmap(v.z), op.xmap(v.w)};
     }
   };
 

@@ -379,6 +379,7 @@ struct WgFgOpT {
   static constexpr bool X_PRODUCT = false;
   static constexpr bool HAS_BIAS = HAS_CTX;  // only the context convs carry biases
   static constexpr bool X_ABSENT_ROWS = HAS_CTX;  // 3C rows fill one and a half 128-row blocks
+  __device__ __forceinline__ float xmap(float v) const { return v; }
   __device__ __forceinline__ const float *a_ptr(int b, int m) const { return dfg.at(b, min(m, 2 * C - 1), 0); }
   __device__ __forceinline__ int a_lo(int m) const { return m < 2 * C ? t_begin : 0; }
   __device__ __forceinline__ int a_hi(int m) const { return m < 2 * C ? t_end : 0; }
@@ -462,6 +463,7 @@ struct WgRsOp {
   static constexpr bool X_PRODUCT = true;  // z = th * sg
   static constexpr bool HAS_BIAS = true;
   static constexpr bool X_ABSENT_ROWS = false;
+  __device__ __forceinline__ float xmap(float v) const { return v; }
   __device__ __forceinline__ const float *a_ptr(int b, int m) const {
     if (m < C) return dxo.p ? dxo.at(b, m, 0) : dskip.at(b, 0, 0);  // absent row: p[0] must exist
     if (m < C + Kc) return dskip.at(b, m - C, 0) - t_base;
@@ -510,6 +512,18 @@ struct WgDenseOp {
     return (m < M && n < N) ? dwm + (size_t)m * N + n : nullptr;
   }
   __device__ __forceinline__ float *db(int m) const { return m < M ? dbv + m : nullptr; }
+  // row descriptors for wgrad2 (the head's column axis starts at t_begin = pad < 4)
+  static constexpr bool X_PRODUCT = false;
+  static constexpr bool HAS_BIAS = true;
+  static constexpr bool X_ABSENT_ROWS = false;
+  __device__ __forceinline__ const float *a_ptr(int b, int m) const { return aact.at(b, min(m, M - 1), 0); }
+  __device__ __forceinline__ int a_lo(int m) const { return m < M ? t_begin : 0; }
+  __device__ __forceinline__ int a_hi(int m) const { return m < M ? t_end : 0; }
+  __device__ __forceinline__ const float *x_ptr(int b, int n) const { return xact.at(b, min(n, N - 1), 0); }
+  __device__ __forceinline__ const float *x_ptr2(int, int) const { return nullptr; }
+  __device__ __forceinline__ int x_lo(int n) const { return n < N ? t_begin : 0; }
+  __device__ __forceinline__ int x_hi(int n) const { return n < N ? t_end : 0; }
+  __device__ __forceinline__ float xmap(float v) const { return IN == IN_LRELU ? leaky(v) : v; }
 };
 
 // ======================================================================
@@ -830,6 +844,20 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       bias_scratch2 = bwd->da1 + slab_floats;
     }
   }
+  // head weight gradients (wgrad2): slabs + bias partials in dfg
+  float *head_slab = bwd->dfg, *head_bias = nullptr;
+  size_t head_slab_floats = (size_t)batch * 2 * C * g.Tp;
+  bool head_scratch_ok = false;
+  {
+    const size_t chunks = (size_t)(g.S + 3 + W2_CHUNK - 1) / W2_CHUNK;
+    const size_t mpad = (size_t)(Q + 127) / 128 * 128;
+    const size_t need_bias = chunks * batch * mpad, need_slab = chunks * batch * mpad * mpad;
+    if (need_bias + need_slab <= head_slab_floats) {
+      head_slab_floats -= need_bias;
+      head_bias = bwd->dfg + head_slab_floats;
+      head_scratch_ok = true;
+    }
+  }
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
@@ -839,7 +867,12 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     WgDenseOp<IN_ID> w2;
     w2.t_begin = g.pad; w2.t_end = g.pad + g.S; w2.M = Q; w2.N = Q; w2.aact = dlog; w2.xact = a1v;
     w2.dwm = gr->head2_w; w2.dbv = gr->head2_b;
-    launch_wgrad(w2, Q, Q, batch, bias_scratch, s);
+    // (slab + bias scratch of wgrad2 live in da1, which conv2's data gradient below writes:
+    // the head uses the dfg tensor instead, free until the layer loop)
+    if (head_scratch_ok)
+      launch_wgrad2<2>(w2, Q, Q, batch, head_bias, head_slab, head_slab_floats, s);
+    else
+      launch_wgrad(w2, Q, Q, batch, bias_scratch, s);
     DenseOp<IN_ID, OUT_MUL_DLRELU, true> d2;
     d2.K = Q; d2.t_begin = g.pad; d2.t_end = g.pad + g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
     d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.pad + g.S;
@@ -850,7 +883,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     WgDenseOp<IN_LRELU> w1;
     w1.t_begin = g.pad; w1.t_end = g.pad + g.S; w1.M = Q; w1.N = Kc; w1.aact = da1; w1.xact = skipv;
     w1.dwm = gr->head1_w; w1.dbv = gr->head1_b;
-    launch_wgrad(w1, Q, Kc, batch, bias_scratch, s);
+    if (head_scratch_ok)
+      launch_wgrad2<1>(w1, Q, Kc, batch, head_bias, head_slab, head_slab_floats, s);
+    else
+      launch_wgrad(w1, Q, Kc, batch, bias_scratch, s);
     DenseOp<IN_ID, OUT_MUL_DLRELU, true> d1;
     d1.K = Q; d1.t_begin = g.pad; d1.t_end = g.pad + g.S; d1.M = Kc; d1.wmat = p->head1_w; d1.ldw = Kc;
     d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.pad + g.S;
