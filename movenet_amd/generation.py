@@ -207,3 +207,58 @@ class RingGenerator:
         self._run(0, self.n_total - 1, self.n_total, logits, choices, logits_t0)
         self.t = self.n_total - 1
         return choices, logits
+
+
+def max_pipe_batch(dims) -> int:
+    """Largest batch one PIPE launch holds co-resident for these dims (0: no PIPE kernel)."""
+    lib = N.lib()
+    if lib.mvn_gen_variant(dims, N.GEN_PIPE, 1) < 0:
+        return 0
+    lo, hi = 1, 512
+    while lo < hi:  # mvn_gen_variant is monotone in the batch
+        mid = (lo + hi + 1) // 2
+        if lib.mvn_gen_variant(dims, N.GEN_PIPE, mid) >= 0:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo
+
+
+class GroupedGenerator:
+    """More sequences than one PIPE launch can hold (24 at config 2): groups of sequences
+    take turns on the pipelines, one launch per group per ``advance``.  Per sequence a PIPE
+    step costs 17.6 us against 78 us for the STREAM kernel, so three launches of 24 + 24 + 16
+    sequences (53 us per step of all 64) still beat one STREAM launch of 64 (78 us).
+    Same interface as ``RingGenerator``; ``samples`` is one (B, n_total) tensor the groups
+    write their row blocks of.  Each group draws from its own Philox key (seed + group)."""
+
+    def __init__(self, layer_size, stack_size, input_channels, residual_channels, skip_channels,
+                 state_dict, batch: int, n_total: int, device, group: int, temperature: float = 0.0,
+                 seed: int = 0, context: Optional[torch.Tensor] = None):
+        self.batch, self.n_total, self.device = int(batch), int(n_total), torch.device(device)
+        self.variant = N.GEN_PIPE
+        self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
+        self.groups, self.bounds = [], []
+        for gi, b0 in enumerate(range(0, self.batch, group)):
+            b1 = min(self.batch, b0 + group)
+            g = RingGenerator(layer_size, stack_size, input_channels, residual_channels, skip_channels,
+                              state_dict, batch=b1 - b0, n_total=n_total, device=device,
+                              variant=N.GEN_PIPE, temperature=temperature,
+                              seed=(int(seed) + 0x9E3779B97F4A7C15 * gi) & (2 ** 64 - 1),
+                              context=None if context is None else context[b0:b1])
+            g.samples = self.samples[b0:b1]  # a contiguous row block of the shared tensor
+            self.groups.append(g)
+            self.bounds.append((b0, b1))
+        self.rf, self.dims = self.groups[0].rf, self.groups[0].dims
+
+    def prime(self, prompt_idx: torch.Tensor) -> None:
+        for g, (b0, b1) in zip(self.groups, self.bounds):
+            g.prime(prompt_idx[b0:b1])
+
+    def advance(self, n_new: int) -> None:
+        for g in self.groups:
+            g.advance(n_new)
+
+    def check_errors(self) -> None:
+        for g in self.groups:
+            g.check_errors()

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
-from .generation import RingGenerator, _require_gpu, _stream_ptr
+from .generation import GroupedGenerator, RingGenerator, _require_gpu, _stream_ptr, max_pipe_batch
 
 # module constants other movenet files import (movenet/wavenet.py:27-31)
 MAX_AUDIO_FRAMES = 160000
@@ -197,11 +197,19 @@ class WaveNet(nn.Module):
         elif context.shape[2] < n_total:
             raise ValueError(f"the upsampled video covers {context.shape[2]} samples, "
                              f"n_samples={n_total} asked for")
-        gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
-                            self.residual_channels, self.skip_channels, state,
-                            batch=idx.shape[0], n_total=n_total, device=audio.device,
-                            variant=self._gen_variant, temperature=float(temperature), seed=seed,
-                            context=context)
+        kw = dict(batch=idx.shape[0], n_total=n_total, device=audio.device,
+                  temperature=float(temperature), seed=seed, context=context)
+        with torch.cuda.device(audio.device):
+            group = max_pipe_batch(self._dims) if self._gen_variant == N.GEN_AUTO else 0
+        if 0 < group < idx.shape[0]:
+            # more sequences than one pipelined launch holds: groups take turns (still faster
+            # per sequence than the weight-streaming kernel)
+            gen = GroupedGenerator(self.layer_size, self.stack_size, self.input_channels,
+                                   self.residual_channels, self.skip_channels, state, group=group, **kw)
+        else:
+            gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
+                                self.residual_channels, self.skip_channels, state,
+                                variant=self._gen_variant, **kw)
         gen.prime(idx[:, :rf])
         gen.advance(n_total - rf)
         return self._one_hot_of(gen.samples, audio.dtype)

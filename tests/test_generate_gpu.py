@@ -181,6 +181,33 @@ def test_config2_pipe_at_full_occupancy():
         _gen(cfg, sd, 25, rf + 1, variant=N.GEN_PIPE)
 
 
+def test_grouped_pipelines_beyond_one_launch():
+    """40 config-2 sequences = groups of 24 + 16 taking turns on the pipelines: greedy output
+    equals one STREAM launch of all 40, and WaveNet.generate picks the grouped form."""
+    from movenet_amd.generation import GroupedGenerator, max_pipe_batch
+    from movenet_amd.utils.weights import make_state_dict
+    from movenet_amd.wavenet import WaveNet
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=6, gain=2.0, head_gain=6.0)
+    rf, B, n_new = 3072, 40, 24
+    assert max_pipe_batch(N.make_dims(10, 3, 256, 64, 64)) == 24
+    pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
+    ref = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_STREAM)
+    ref.prime(pidx)
+    ref.advance(n_new)
+    sdd = {k: v.to(DEV) for k, v in sd.items()}
+    g = GroupedGenerator(**cfg, state_dict=sdd, batch=B, n_total=rf + n_new, device=DEV, group=24)
+    assert [b - a for a, b in g.bounds] == [24, 16]
+    g.prime(pidx)
+    g.advance(n_new)
+    g.check_errors()
+    assert torch.equal(g.samples, ref.samples)
+    model = WaveNet(**cfg)
+    model.load_state_dict(sd, strict=False)
+    out = model.to(DEV).generate(one_hot(pidx.cpu(), 256).to(DEV), n_samples=rf + n_new, temperature=0.0)
+    assert torch.equal(out.argmax(1).to(torch.int32), ref.samples)
+
+
 def test_bad_input_raises():
     from movenet_amd.wavenet import WaveNet
     model = WaveNet(2, 2, 64, 16, 16).to(DEV)
