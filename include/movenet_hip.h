@@ -289,7 +289,8 @@ int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, i
  * accuracy = mean of [first argmax_q probs[b,:,s] == target[b,s]].
  *   probs (B, Q, S) fp32, target (B, S) int64 class indices.
  * forward: per-workgroup partial sums, loss_part / correct_part have mvn_ce_parts(B,S)
- *   entries each (summed by the caller in a fixed order: deterministic).
+ *   entries each, ZEROED by the caller (not every slot is written for every shape) and
+ *   summed by it in a fixed order: deterministic.
  * backward: dprobs = scale * upstream * (softmax_q(probs) - onehot(target)); scale = 1/(B*S) for
  *   the mean, `upstream` = device pointer to the scalar gradient of the loss (NULL: 1), read
  *   by the kernel so that the host never has to synchronise for it. */

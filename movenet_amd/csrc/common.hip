@@ -152,13 +152,101 @@ __global__ __launch_bounds__(256) void ce_probs_bwd_kernel(const float *__restri
   }
 }
 
+// single-pass forms for Q <= 256 (see softmax_cols_kernel in sequence.hip: 64 columns per
+// workgroup, wave w holds class rows [64w, 64w+64) of them in registers, lane = column)
+constexpr int CEQ = 64;
+__device__ __forceinline__ float ce_col_reduce(float v, float (*part)[64], int wave, int lane, bool is_max) {
+  part[wave][lane] = v;
+  __syncthreads();
+  const float a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+// BWD = false: loss / correct partial sums per workgroup; BWD = true: dprobs
+template <bool BWD>
+__global__ __launch_bounds__(256) void ce_probs_cols_kernel(const float *__restrict__ p,
+                                                            const long long *__restrict__ target, int Q,
+                                                            int S, float scale,
+                                                            const float *__restrict__ upstream,
+                                                            float *__restrict__ out_f,
+                                                            int32_t *__restrict__ correct_part) {
+  __shared__ float part[4][64];
+  __shared__ int argp[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int sidx = blockIdx.x * 64 + lane;
+  const bool live = sidx < S;
+  const float *col = p + (size_t)b * Q * S + (live ? sidx : 0);
+  float v[CEQ];
+  float m = -INFINITY;
+  int arg = 0;
+#pragma unroll
+  for (int i = 0; i < CEQ; ++i) {
+    const int q = CEQ * wave + i;
+    v[i] = (live && q < Q) ? col[(size_t)q * S] : -INFINITY;
+    if (v[i] > m) {  // strict: first maximum inside this wave's rows
+      m = v[i];
+      arg = q;
+    }
+  }
+  const float wave_m = m;
+  m = ce_col_reduce(m, part, wave, lane, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < CEQ; ++i) {
+    v[i] = expf(v[i] - m);
+    sum += v[i];
+  }
+  sum = ce_col_reduce(sum, part, wave, lane, false);
+  const long long tg = live ? target[(size_t)b * S + sidx] : 0;
+  const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
+  if (BWD) {
+    if (!live) return;
+    if (upstream) scale *= *upstream;
+    const float inv = 1.0f / sum;
+    float *dcol = out_f + (size_t)b * Q * S + sidx;
+#pragma unroll
+    for (int i = 0; i < CEQ; ++i) {
+      const int q = CEQ * wave + i;
+      if (q < Q) dcol[(size_t)q * S] = scale * (v[i] * inv - (q == tq ? 1.0f : 0.0f));
+    }
+  } else {
+    // first global maximum: the lowest wave whose own maximum equals the column maximum
+    argp[wave][lane] = wave_m == m ? arg : 0x7fffffff;
+    // the target's probability sits in exactly one wave's registers
+    float pt = 0.f;
+    {
+      const float *pc = col + (size_t)tq * S;
+      if (live && wave == tq / CEQ) pt = *pc;
+    }
+    const float pt_all = ce_col_reduce(pt, part, wave, lane, false);
+    __syncthreads();
+    float loss = 0.f;
+    int ok = 0;
+    if (wave == 0 && live) {
+      const int a0 = min(min(argp[0][lane], argp[1][lane]), min(argp[2][lane], argp[3][lane]));
+      loss = (m + logf(sum)) - pt_all;
+      ok = a0 == tq;
+    }
+    if (wave == 0) {
+      loss = wave_sum(loss);
+      const float okf = wave_sum((float)ok);
+      if (lane == 0) {
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+        out_f[wg] = loss;
+        correct_part[wg] = (int)okf;
+      }
+    }
+  }
+}
+
 }  // namespace mvn
 
 extern "C" {
 
 int mvn_ce_parts(int batch, int s_len) {
   if (batch < 0 || s_len < 0) return 0;
-  return batch * ((s_len + 255) / 256);
+  return batch * ((s_len + 63) / 64);
 }
 
 int mvn_ce_on_probs_forward(const float *probs, const long long *target, int batch, int classes,
@@ -168,8 +256,15 @@ int mvn_ce_on_probs_forward(const float *probs, const long long *target, int bat
     return MVN_ERR_BAD_ARG;
   }
   if (batch == 0 || s_len == 0) return MVN_OK;
-  hipLaunchKernelGGL(mvn::ce_probs_fwd_kernel, dim3((s_len + 255) / 256, batch), dim3(256), 0,
-                     (hipStream_t)stream, probs, target, classes, s_len, loss_part, correct_part);
+  // partial-sum slots: mvn_ce_parts() = one per 64-column workgroup (the wide-Q form uses a
+  // quarter of them: the caller zero-fills the arrays)
+  if (classes <= 4 * mvn::CEQ)
+    hipLaunchKernelGGL(mvn::ce_probs_cols_kernel<false>, dim3((s_len + 63) / 64, batch), dim3(256), 0,
+                       (hipStream_t)stream, probs, target, classes, s_len, 0.f, nullptr, loss_part,
+                       correct_part);
+  else
+    hipLaunchKernelGGL(mvn::ce_probs_fwd_kernel, dim3((s_len + 255) / 256, batch), dim3(256), 0,
+                       (hipStream_t)stream, probs, target, classes, s_len, loss_part, correct_part);
   return mvn::check_hip(hipGetLastError(), "ce_on_probs_forward");
 }
 
@@ -181,8 +276,12 @@ int mvn_ce_on_probs_backward(const float *probs, const long long *target, int ba
     return MVN_ERR_BAD_ARG;
   }
   if (batch == 0 || s_len == 0) return MVN_OK;
-  hipLaunchKernelGGL(mvn::ce_probs_bwd_kernel, dim3((s_len + 255) / 256, batch), dim3(256), 0,
-                     (hipStream_t)stream, probs, target, classes, s_len, scale, upstream, dprobs);
+  if (classes <= 4 * mvn::CEQ)
+    hipLaunchKernelGGL(mvn::ce_probs_cols_kernel<true>, dim3((s_len + 63) / 64, batch), dim3(256), 0,
+                       (hipStream_t)stream, probs, target, classes, s_len, scale, upstream, dprobs, nullptr);
+  else
+    hipLaunchKernelGGL(mvn::ce_probs_bwd_kernel, dim3((s_len + 255) / 256, batch), dim3(256), 0,
+                       (hipStream_t)stream, probs, target, classes, s_len, scale, upstream, dprobs);
   return mvn::check_hip(hipGetLastError(), "ce_on_probs_backward");
 }
 

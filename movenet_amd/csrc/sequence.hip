@@ -607,6 +607,78 @@ __global__ void softmax_bwd_kernel(const float *__restrict__ p, const float *__r
   }
 }
 
+// ---- single-pass column kernels (Q <= 256): a workgroup owns 64 columns, wave w the class
+// rows [64w, 64w+64) of them, lane = column.  A thread keeps its quarter of a column in 64
+// registers, so the tensor is read once and written once (the thread-per-column forms above
+// walk the column two or three times: 636 MB instead of 212 MB at config 2); the column-wide
+// maximum / sum go through 1 KB of LDS.
+constexpr int CQ = 64;  // rows per wave = registers per thread
+__device__ __forceinline__ float col_reduce(float v, float (*part)[64], int wave, int lane, bool is_max) {
+  part[wave][lane] = v;
+  __syncthreads();
+  const float a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+__global__ __launch_bounds__(256) void softmax_cols_kernel(float *__restrict__ y, int Q, int S) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int s = blockIdx.x * 64 + lane;
+  const bool live = s < S;
+  float *col = y + (size_t)b * Q * S + (live ? s : 0);
+  float v[CQ];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int q = CQ * wave + i;
+    v[i] = (live && q < Q) ? col[(size_t)q * S] : -INFINITY;
+    m = fmaxf(m, v[i]);
+  }
+  m = col_reduce(m, part, wave, lane, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    v[i] = expf(v[i] - m);  // exp(-inf) = 0 for the padding rows
+    sum += v[i];
+  }
+  sum = col_reduce(sum, part, wave, lane, false);
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int q = CQ * wave + i;
+    if (q < Q) col[(size_t)q * S] = v[i] / sum;
+  }
+}
+
+// dlogit = p * (dout - sum_q dout*p), zero for columns >= S_out (normalize != 0 only)
+__global__ __launch_bounds__(256) void softmax_bwd_cols_kernel(const float *__restrict__ p,
+                                                               const float *__restrict__ dout, Act dlogit,
+                                                               int Q, int S_out, int S, int pad) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int s = blockIdx.x * 64 + lane;
+  const bool live = s < S_out;
+  const size_t off = (size_t)b * Q * S_out + (live ? s : 0);
+  float pv[CQ], dv[CQ];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int q = CQ * wave + i;
+    const bool ok = live && q < Q;
+    pv[i] = ok ? p[off + (size_t)q * S_out] : 0.f;
+    dv[i] = ok ? dout[off + (size_t)q * S_out] : 0.f;
+    dot += dv[i] * pv[i];
+  }
+  dot = col_reduce(dot, part, wave, lane, false);
+  if (s >= S) return;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int q = CQ * wave + i;
+    if (q < Q) *dlogit.at(b, q, s + pad) = live ? pv[i] * (dv[i] - dot) : 0.f;
+  }
+}
+
 // dilation queues <- saved layer inputs (state layout: generate.hip ring_offset)
 __global__ void ring_fill_kernel(const float *__restrict__ acts, long long act_stride, Act view,
                                  float *__restrict__ state, long long state_per_seq, int C,
@@ -792,9 +864,14 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     h2.yout = act_view(out - g.pad, batch, Q, S_out);
     h2.t_out_end = g.pad + S_out; h2.aligned_out = 0;
     launch_gemm_staged(h2, Q, batch, s);
-    if (normalize)
-      hipLaunchKernelGGL(softmax_kernel, dim3((S_out + 255) / 256, batch), dim3(256), 0, s, out, Q,
-                         S_out);
+    if (normalize) {
+      if (Q <= 4 * CQ)
+        hipLaunchKernelGGL(softmax_cols_kernel, dim3((S_out + 63) / 64, batch), dim3(256), 0, s, out, Q,
+                           S_out);
+      else
+        hipLaunchKernelGGL(softmax_kernel, dim3((S_out + 255) / 256, batch), dim3(256), 0, s, out, Q,
+                           S_out);
+    }
   }
   return check_hip(hipGetLastError(), "mvn_forward");
 }
@@ -861,7 +938,11 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((g.S + 255) / 256, batch), dim3(256), 0, s, out, dout,
+  if (normalize && Q <= 4 * CQ)
+    hipLaunchKernelGGL(softmax_bwd_cols_kernel, dim3((g.S + 63) / 64, batch), dim3(256), 0, s, out, dout,
+                       dlog, Q, S_out, g.S, g.pad);
+  else
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((g.S + 255) / 256, batch), dim3(256), 0, s, out, dout,
                      dlog, Q, S_out, g.S, normalize, g.pad);
   {  // head conv2: weight grad, then data grad (x lrelu'(a1))
     WgDenseOp<IN_ID> w2;

@@ -92,7 +92,7 @@ def test_bad_arguments_are_refused_before_any_launch():
 def test_loss_kernels_argument_checks():
     """Row F3 entry points: sizes and refusals that need no GPU."""
     lib = N.lib()
-    assert lib.mvn_ce_parts(16, 12928) == 16 * 51      # one partial sum per 256-column workgroup
+    assert lib.mvn_ce_parts(16, 12928) == 16 * 202     # one partial sum per 64-column workgroup
     assert lib.mvn_ce_parts(0, 100) == 0 and lib.mvn_ce_parts(3, 0) == 0 and lib.mvn_ce_parts(-1, 5) == 0
     assert lib.mvn_ce_on_probs_forward(None, None, 2, 64, 10, None, None, None) == N.MVN_ERR_BAD_ARG
     assert "mvn_ce_on_probs_forward" in N.last_error()
