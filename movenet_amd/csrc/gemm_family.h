@@ -1,6 +1,7 @@
-// The two MFMA kernel families every convolution-shaped product of the full-sequence
-// path is built from (see sequence.hip for the description), shared by sequence.hip
-// (decoder) and video.hip (video encoder / learned upsampler).
+// The MFMA kernel families every convolution-shaped product of the full-sequence path is
+// built from (see sequence.hip for the description), shared by sequence.hip (decoder) and
+// video.hip (video encoder / learned upsampler): gemm_wx_kernel / gemm_wx_staged_kernel
+// (Y = W X over time), wgrad_kernel / wgrad2_kernel (dW = A X^T, K = time) and their reducers.
 #pragma once
 #include "common.h"
 

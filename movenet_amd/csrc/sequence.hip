@@ -7,13 +7,16 @@
 // Everything convolution-shaped here is a "weights x time" product
 //     Y[b][m][t] = sum_k W[m][k] * X[b][k][t (+shift_k)]
 // with tiny M,K (16..256 channels) and long t, so ONE MFMA kernel family
-// (gemm_wx_kernel<Op>) serves every forward conv and every data-gradient, and
-// ONE family (wgrad_kernel<Op>) serves every weight gradient (a product over
-// time, split across workgroups and combined with fp32 atomics).  The Op
-// functor supplies operand addressing (taps, transposes, f/g row pairing,
-// validity masks) and the fused epilogue (gating, residual add, skip
-// accumulation, leaky-ReLU and its derivative...).  Both use
-// v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain.
+// (gemm_wx_staged_kernel<Op>, LDS-staged float4 epilogue) serves every forward
+// conv and every data-gradient, and ONE family serves every weight gradient, a
+// product over time split across workgroups: wgrad2_kernel<Op> (16-byte operand
+// traffic, per-workgroup slabs reduced in a fixed order) for the layers and the
+// head, wgrad_kernel<Op> (64 x 64 tiles, fp32 atomics) for the dense causal conv
+// and the video upsampler.  The Op functor supplies operand addressing (taps,
+// transposes, f/g row pairing, validity ranges) and the fused epilogue (gating,
+// residual add, skip accumulation, leaky-ReLU and its derivative...).  All use
+// v_mfma_f32_32x32x2_f32: exact fp32 products and sums (wgrad2 permutes the order
+// of the sum over time inside groups of 8).
 //
 // Activations use an ABSOLUTE time axis (see movenet_hip.h): tensor (B, ch, Tp),
 // column t = input time t, layer l's input valid for t >= A_l.
