@@ -14,13 +14,19 @@ random-init weights.  One STEP = one pass of the hot path over the batch:
 the prompt happens before the timed region and is reported separately.
 Multi-GPU = independent clips per rank (weak scaling), no data-path collective.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself
+(one child process per device, spawned BEFORE anything touches the GPU) and relays rank 0's line.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,8 +37,12 @@ sys.path.insert(0, ROOT)
 
 CFG = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
 BATCH = 16
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PMC_BYTES_PER_STEP_SEQ = (19810.6 + 14644.8) * 1024 / (16 * 16000)  # measured, see roofline.traffic
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (vector)" = "Peak FP32 (matrix)"
+# HBM-side bytes per generated sample per sequence of gen_pipe_kernel<64>, from separate
+# rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an earlier run of this same command; NOT
+# measured by the run that prints the line (roofline.traffic_source says so)
+PMC_TRAFFIC = {"bytes_per_step_seq": (19810.6 + 14644.8) * 1024 / (16 * 16000),
+               "source": "profiles/r01b_pmc_gen_pipe_fetch_write.csv"}
 
 
 def flop_per_sample(cfg) -> int:
@@ -74,6 +84,41 @@ def host_cores() -> int:
     return min(n, 64)
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_cached_line(sd, n_timed: int = 4000, n_warm: int = 200):
+    """The SAME ring-buffer (cached) algorithm the HIP kernels run, on the host cores: the C
+    restatement oracle/ring_oracle.c (gcc -O3 -march=x86-64-v3, OpenMP over the 16 sequences;
+    pinned to the reference's greedy output by tests/test_ring_c_oracle.py).  Reported beside
+    the naive windowed baseline so that the algorithmic gain (windowed -> cached) and the
+    hardware gain (CPU -> MI355X on the same algorithm) can be told apart."""
+    import numpy as np
+    from oracle import ring_c
+    from oracle import wavenet_oracle as O
+    dims = O.Dims(**CFG)
+    threads = min(host_cores(), BATCH)
+    ring = ring_c.RingC(sd, dims, BATCH)
+    n = n_warm + n_timed + 1
+    samples = np.random.default_rng(0).integers(0, CFG["input_channels"], size=(BATCH, n)).astype(np.int32)
+    ring.run(samples, 1, 0, n_warm, threads)           # free-running greedy from one given sample
+    t0 = time.perf_counter()
+    ring.run(samples, 1, n_warm, n_warm + n_timed, threads)
+    dt = time.perf_counter() - t0
+    return {"value": BATCH * n_timed / dt, "unit": "samples/s", "cores": threads, "cpu_model": cpu_model(),
+            "kind": "port (cached / ring-buffer algorithm, C: oracle/ring_oracle.c)",
+            "sample": f"{n_timed} greedy steps at batch {BATCH} after {n_warm} warm-ups, {dt:.2f} s",
+            "us_per_step": dt / n_timed * 1e6}
+
+
 def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
     """The reference's NAIVE windowed generate (wavenet.py:217-237) on the host
     cores, via the CPU oracle (kind "port": pinned bit-exact to the reference in
@@ -104,6 +149,7 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
         "value": BATCH * n_timed / dt,
         "unit": "samples/s",
         "cores": cores,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"{n_timed} steady-state steps of the reference's naive windowed generate "
                   f"(RF={rf} window forward per sample) at batch {BATCH} after {n_warm} warm-ups, "
@@ -113,6 +159,7 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
 
 
 def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
+    import torch.distributed as dist
     """Secondary metric M2 (BASELINE.json): train-step tokens/sec on config 2 --
     forward (probabilities), cross_entropy on them (Q2), backward through the HIP
     kernels, one flat gradient all-reduce when world > 1, AdamW.  Token = one
@@ -143,7 +190,6 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
     t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -161,6 +207,14 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # replica consistency evidence (used by the two-process -m gpu test): after identical
+    # optimizer steps on all-reduced gradients every rank must hold the same parameters
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+    digest = hashlib.sha256(flat.tobytes()).hexdigest()
+    digests = [digest]
+    if world > 1:
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
     tokens = world * batch * (t_len - rf) * steps
     # 5,441,508 FLOP per token (fwd + bwd = 3 x forward MACs x 2)
     flop_per_token = 5441508
@@ -169,8 +223,67 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
             "ms_per_step": dt / steps * 1e3, "global_batch": world * batch, "seq_len": t_len,
             "tokens_per_step": world * batch * (t_len - rf), "optimizer": "AdamW", "dtype": "f32",
             "loss": float(loss.detach()),
-            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf / world / FP32_MATRIX_PEAK_TFLOPS}}
+            "param_sha256_per_rank": digests, "allreduce_path": sync.last_path,
+            "allreduce_floats": sync.last_floats,
+            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / world / FP32_PEAK_TFLOPS}}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start one child per
+    device (same command line, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), relay rank 0's JSON
+    line.  Runs before this process has made any GPU call; the children are ordinary child
+    processes (no exec of an initialised process)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def extra_lines(dev, sd, rf, n_new, rank):
+    """Figures quoted beside the headline (same workload, outside the timed steps): sampling at
+    the reference's default temperature 1.0, and one END-TO-END WaveNet.generate call
+    (one-hot prompt in HBM -> indices -> priming -> 16000 steps -> one-hot out)."""
+    from movenet_amd.generation import RingGenerator
+    from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices
+    from movenet_amd.wavenet import WaveNet
+    prompt = synthetic_indices(BATCH, rf, CFG["input_channels"], 1234 + rank).to(dev)
+    out = {}
+    g = RingGenerator(**CFG, state_dict=sd, batch=BATCH, n_total=rf + 2 * n_new + 1, device=dev,
+                      temperature=1.0, seed=1)
+    g.prime(prompt)
+    g.advance(n_new)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    g.advance(n_new)
+    g.check_errors()
+    out["temperature_1.0_samples_per_s"] = BATCH * n_new / (time.perf_counter() - t0)
+    del g
+    model = WaveNet(**CFG)
+    model.load_state_dict(make_state_dict(**CFG, seed=0))
+    model.to(dev)
+    audio = one_hot(prompt, CFG["input_channels"])
+    model.generate(audio, n_samples=rf + 64, temperature=0.0)  # code objects, allocator
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    y = model.generate(audio, n_samples=rf + n_new, temperature=0.0)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert y.shape == (BATCH, CFG["input_channels"], rf + n_new)
+    out["end_to_end_generate_samples_per_s"] = BATCH * n_new / dt
+    out["end_to_end_generate_ms"] = dt * 1e3
+    out["end_to_end_fallback_variant"] = model.last_generate_fallback
+    return out
 
 
 def main():
@@ -182,14 +295,15 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream, 3 pipe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the T=1.0 and end-to-end lines")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            raise SystemExit(spawn_ranks(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
@@ -268,6 +382,14 @@ def main():
     flops_per_launch = flop_per_sample(CFG) * BATCH * n_new
     achieved = flops_per_launch / avg_kernel_s / 1e12
 
+    extras = None
+    if rank == 0 and not args.no_extras:
+        try:
+            extras = extra_lines(dev, sd, rf, n_new, rank)
+            log(f"rank 0: extras {extras}")
+        except Exception as e:
+            extras = {"error": f"{type(e).__name__}: {e}"}
+
     train = None
     if not args.no_train_leg:
         try:
@@ -307,16 +429,20 @@ def main():
             "prime_ms": prime_ms,
             "prime_first_call_ms": prime_cold_ms,
             "roofline": {
-                "bound": "mfma",
+                # the kernel issues v_pk_fma_f32 (fp32 VECTOR FMA), no MFMA: the roof it is
+                # priced against is the fp32 vector peak, numerically the same 157.3 TFLOP/s
+                # as the fp32-matrix peak SURVEY 8(d) names as the paper bound
+                "bound": "valu_fp32",
                 "achieved": achieved,
-                "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE 19811 KB as
-                # reported -- 4/8-byte accesses, the guide's x2 correction is calibrated for
-                # 16-B streams only -- + WRITE_SIZE 14645 KB per 16000-step launch of 16
-                # sequences: profiles/r01b_pmc_gen_pipe_fetch_write.csv), scaled to this launch
-                "traffic": (PMC_BYTES_PER_STEP_SEQ * BATCH * n_new) if variant_used == 3 else None,
+                "frac": achieved / FP32_PEAK_TFLOPS,
+                # HBM-side bytes per launch: FETCH_SIZE (as reported: 4/8-byte accesses, the
+                # guide's x2 correction is calibrated for 16-B streams only) + WRITE_SIZE of
+                # separate rocprofv3 --pmc passes, scaled to this launch
+                "traffic": (PMC_TRAFFIC["bytes_per_step_seq"] * BATCH * n_new) if variant_used == 3 else None,
+                "traffic_source": (f"constant from {PMC_TRAFFIC['source']} (earlier --pmc passes of this "
+                                   "command); not measured by this run") if variant_used == 3 else None,
                 "traffic_unit": "bytes per launch (HBM side; the 12.6 MB of dilation queues stay in L2/MALL)",
                 "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>"}[variant_used],
                 "flop_per_launch": flops_per_launch,
@@ -325,10 +451,16 @@ def main():
             },
         }
         out["train_step"] = train
+        out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(sd_cpu)
             out["cpu_baseline"] = cb
+            cached = cpu_cached_line(sd_cpu)
+            out["cpu_cached_algorithm"] = cached
+            # naive CPU -> cached CPU = the algorithmic change (Q4); cached CPU -> this = hardware
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            out["speedup_split"] = {"algorithm_cached_over_windowed_cpu": cached["value"] / cb["value"],
+                                    "hardware_gpu_over_cached_cpu": value / cached["value"]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -23,6 +23,10 @@ inline long long dilation_sum(const mvn_dims *d) {
   return (long long)d->stack_size * ((1LL << d->layer_size) - 1);
 }
 int validate_dims(const mvn_dims *d);
+// Raise a kernel's dynamic-LDS limit to the CU's 160 KiB on the CURRENT device, once per
+// (kernel, device): hipFuncSetAttribute applies to the current device's copy of the code
+// object, so a per-process flag would leave a second device at the 64 KiB default.
+int ensure_max_dynamic_lds(const void *kernel, const char *what);
 
 // ---- device side --------------------------------------------------------
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }

@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace mvn {
 
@@ -18,6 +20,21 @@ int check_hip(hipError_t e, const char *what) {
   if (e == hipSuccess) return MVN_OK;
   set_error("%s: %s", what, hipGetErrorString(e));
   return MVN_ERR_LAUNCH;
+}
+
+int ensure_max_dynamic_lds(const void *kernel, const char *what) {
+  static std::mutex mu;
+  static std::map<const void *, uint64_t> done;  // kernel -> bitmask of device ordinals
+  int dev = 0;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return MVN_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(mu);
+  uint64_t &mask = done[kernel];
+  if (dev >= 0 && dev < 64 && ((mask >> dev) & 1u)) return MVN_OK;
+  int rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                     what);
+  if (rc) return rc;
+  if (dev >= 0 && dev < 64) mask |= (uint64_t)1 << dev;  // ordinals >= 64: set it every time
+  return MVN_OK;
 }
 
 int validate_dims(const mvn_dims *d) {

@@ -892,27 +892,15 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
     const size_t lds =
         sizeof(float) * ((size_t)mvn::s64::EMB_FLOATS + 128 + 256 + 64 + 256 + 64 + 256 + 32 + 8 +
                          (size_t)a.L * 64);
-    static bool attr_set = false;
-    if (!attr_set) {
-      int rc = mvn::check_hip(
-          hipFuncSetAttribute((const void *)mvn::gen_stream64_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-          "hipFuncSetAttribute(gen_stream64)");
-      if (rc) return rc;
-      attr_set = true;
-    }
+    int rc = mvn::ensure_max_dynamic_lds((const void *)mvn::gen_stream64_kernel,
+                                         "hipFuncSetAttribute(gen_stream64)");
+    if (rc) return rc;
     hipLaunchKernelGGL(mvn::gen_stream64_kernel, dim3(batch), dim3(256), lds, (hipStream_t)stream, a);
   } else {
     const size_t lds = mvn::generic_lds_bytes(dims);
-    static bool attr_set = false;
-    if (!attr_set) {
-      int rc = mvn::check_hip(
-          hipFuncSetAttribute((const void *)mvn::gen_generic_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-          "hipFuncSetAttribute(gen_generic)");
-      if (rc) return rc;
-      attr_set = true;
-    }
+    int rc = mvn::ensure_max_dynamic_lds((const void *)mvn::gen_generic_kernel,
+                                         "hipFuncSetAttribute(gen_generic)");
+    if (rc) return rc;
     hipLaunchKernelGGL(mvn::gen_generic_kernel, dim3(batch), dim3(mvn::generic_threads(dims)), lds,
                        (hipStream_t)stream, a);
   }

@@ -20,6 +20,8 @@
 //
 // Reference arithmetic: see generate.hip (movenet/wavenet.py:217-237,
 // movenet/modules.py:19-30, :67-93, :139-142).
+#include <cstdlib>
+
 #include "common.h"
 #include "gen_common.h"
 
@@ -86,8 +88,11 @@ __device__ unsigned long long g_fine[16][16][64][8];
 // placement-independent form.  Placement only ever selects between two correct forms.
 __device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v, bool same_xcd) {
   const u64 x = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+  // same XCD: a relaxed WORKGROUP-scope atomic store -- on gfx950 the same write-through
+  // global_store_dwordx2 as a plain store (line kept in the shared L2), but an atomic in the
+  // memory model: never deferred, merged or torn by the compiler
   if (same_xcd)
-    *g = x;
+    __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else
     __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -329,6 +334,10 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
     if (slot >= SPX || s >= NS) return;
   }
   if (b >= nb) return;
+  // The status word is STICKY: raised by a timed-out hand-off, cleared only when the host
+  // zeroes the generator state (RingGenerator.reset).  A launch that finds it raised does
+  // nothing, so a failure in one advance() chunk cannot be papered over by the next one.
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const int L = a.L;
   const int s_next = s + 1 == NS ? 0 : s + 1;
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
@@ -866,29 +875,63 @@ int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hi
                                     : pipe_pack_ctx_t<128>(d, p, ctx_section, s);
 }
 
+// Co-residency: every stage of every pipeline polls its predecessor, so ALL workgroups of the
+// grid must be resident at once.  The launch is cooperative -- the runtime checks the grid
+// against the kernel's occupancy (hipErrorCooperativeLaunchTooLarge instead of a silent
+// dead wait) and does not run it next to another kernel of this process -- and the host
+// repeats the same check with the occupancy query.  Another PROCESS holding CUs can still
+// starve a stage: then the bounded spins raise the sticky status word and the caller
+// (WaveNet.generate) reruns the call on a kernel without hand-offs.
 template <int CC>
 static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
   using P = PipeCfg<CC>;
-  const int NS = pipe_stages(d);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void *)gen_pipe_kernel<CC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                       "hipFuncSetAttribute(gen_pipe)");
-    if (rc) return rc;
-    attr_set = true;
-  }
-  const size_t hand_bytes = pipe_hand_floats(d, batch) * sizeof(float);
-  // every polled word is re-initialised by a memset node ahead of each launch
-  int rc = check_hip(hipMemsetAsync(hand, 0, hand_bytes, s), "hipMemsetAsync(hand-off area)");
+  int NS = pipe_stages(d);
+  const void *fn = (const void *)gen_pipe_kernel<CC>;
+  int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_pipe)");
   if (rc) return rc;
-  u64 *gran = (u64 *)hand;
-  unsigned *err = (unsigned *)(hand + (size_t)batch * NS * P::GRAN * 2);
+  const size_t lds_bytes = P::LDS_FLOATS * sizeof(float);
   // grid: 8 workgroups (one per XCD) per slot; see the kernel's (xcd, slot) -> (b, s) map
   const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS;
   const int slots = NS <= PIPE_XCD_CUS ? (batch + 7) / 8 * NS : (NS + XS - 1) / XS;
-  hipLaunchKernelGGL(gen_pipe_kernel<CC>, dim3(slots * 8), dim3(P::NT),
-                     P::LDS_FLOATS * sizeof(float), s, a, gran, err, NS, batch);
+  int dev = 0, cus = 0, per_cu = 0, coop = 0;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||
+      check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev),
+                "hipDeviceGetAttribute(CUs)") ||
+      check_hip(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev),
+                "hipDeviceGetAttribute(cooperative)") ||
+      check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P::NT, lds_bytes),
+                "hipOccupancyMaxActiveBlocksPerMultiprocessor(gen_pipe)"))
+    return MVN_ERR_LAUNCH;
+  if (per_cu < 1 || slots * 8 > per_cu * cus) {
+    set_error("PIPE variant: grid of %d workgroups is not co-resident (%d per CU x %d CUs)",
+              slots * 8, per_cu, cus);
+    return MVN_ERR_UNSUPPORTED;
+  }
+  // Every polled word is re-initialised by memset nodes ahead of each launch: the granules
+  // and the placement words -- NOT the 16 flag words between them (the sticky status word).
+  const size_t gran_floats = (size_t)batch * NS * P::GRAN * 2;
+  unsigned *err = (unsigned *)(hand + gran_floats);
+  const size_t tail_floats = pipe_hand_floats(d, batch) - gran_floats - 16;
+  rc = check_hip(hipMemsetAsync(hand, 0, gran_floats * sizeof(float), s), "hipMemsetAsync(granules)");
+  if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(err + 16, 0, tail_floats * sizeof(float), s),
+                 "hipMemsetAsync(placement words)");
+  if (rc) return rc;
+  u64 *gran = (u64 *)hand;
+  GenArgs args = a;
+  int nb = batch;
+  static const bool plain = [] {  // MOVENET_PIPE_PLAIN_LAUNCH=1: diagnostics only
+    const char *e = getenv("MOVENET_PIPE_PLAIN_LAUNCH");
+    return e && e[0] == '1';
+  }();
+  if (coop && !plain) {
+    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
+    return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(P::NT), kargs,
+                                                (unsigned)lds_bytes, s),
+                     "mvn_generate(pipe, cooperative launch)");
+  }
+  hipLaunchKernelGGL(gen_pipe_kernel<CC>, dim3(slots * 8), dim3(P::NT), lds_bytes, s, args, gran, err,
+                     NS, nb);
   return check_hip(hipGetLastError(), "mvn_generate(pipe)");
 }
 

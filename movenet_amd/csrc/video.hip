@@ -187,14 +187,8 @@ int mvn_upsample_video(const mvn_dims *dims, const mvn_video_params *vp, const f
   const int C = dims->residual_channels, F = frames;
   const int FB = cin == 1 ? 4 : 1;
   const size_t lds = sizeof(float) * (size_t)FB * cin * kPix;
-  static bool attr_set = false;
-  if (!attr_set) {
-    rc = check_hip(hipFuncSetAttribute((const void *)video_conv_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                   "hipFuncSetAttribute(video_conv)");
-    if (rc) return rc;
-    attr_set = true;
-  }
+  rc = ensure_max_dynamic_lds((const void *)video_conv_kernel, "hipFuncSetAttribute(video_conv)");
+  if (rc) return rc;
   Act encv = act_view(enc, batch, C, mvn_padded_len(F));
   hipLaunchKernelGGL(video_conv_kernel, dim3((F + FB - 1) / FB, batch), dim3(256), lds, s, video,
                      vp->conv_w, vp->conv_b, encv, C, cin, F, FB);

@@ -13,6 +13,12 @@ import torch
 from . import _native as N
 
 
+class PipeHandoffTimeout(RuntimeError):
+    """A stage of the PIPE generator waited for its predecessor beyond the spin bound: its
+    workgroups were not co-resident (another process or stream held CUs).  The samples of
+    that call are NOT valid."""
+
+
 def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -140,14 +146,25 @@ class RingGenerator:
         self.state.zero_()
         self.t = 0
 
+    def status_word(self) -> Optional[torch.Tensor]:
+        """The PIPE variant's sticky status word (a 1-element int32 view into the state), or
+        None.  Non-zero since the last ``reset()`` = a hand-off timed out; every later launch
+        is then a no-op until the state is zeroed again."""
+        if self.variant != N.GEN_PIPE:
+            return None
+        word = self.lib.mvn_gen_status_offset(self.dims, self.batch)
+        return self.state[word:word + 1].view(torch.int32)
+
     def check_errors(self) -> None:
-        """Synchronise and raise if a PIPE hand-off timed out (workgroups of a
-        pipeline not co-resident, e.g. another kernel occupying the CUs)."""
+        """Synchronise and raise ``PipeHandoffTimeout`` if a PIPE hand-off timed out since
+        the last ``reset()`` (workgroups of a pipeline not co-resident, e.g. another process
+        occupying CUs).  Every product path calls this before handing samples on."""
         torch.cuda.current_stream(self.device).synchronize()
-        if self.variant == N.GEN_PIPE:
-            word = self.lib.mvn_gen_status_offset(self.dims, self.batch)
-            if int(self.state[word:word + 1].view(torch.int32)[0].item()) != 0:
-                raise RuntimeError("movenet_amd: PIPE generator hand-off timed out")
+        word = self.status_word()
+        if word is not None and int(word[0].item()) != 0:
+            raise PipeHandoffTimeout(
+                "movenet_amd: PIPE generator hand-off timed out (pipeline stages not "
+                "co-resident); the samples of this call are not valid")
 
     def _run(self, t_begin: int, t_end: int, n_given: int, logits_out=None, choices_out=None,
              logits_t0: int = 0) -> None:
@@ -209,6 +226,32 @@ class RingGenerator:
         return choices, logits
 
 
+def auto_plan(dims, batch: int, has_context: bool):
+    """What MVN_GEN_AUTO means at the Python level for ``batch`` sequences: returns
+    ("single", variant) for one launch or ("grouped", group) for groups of ``group``
+    sequences taking turns on the PIPE pipelines.
+
+    Chosen on measured per-step cost: a PIPE step costs the same for
+    1..group sequences, so n groups cost n x t_pipe per step of all of them, against ONE
+    launch of the next-best kernel that holds every sequence:
+      C=K=64  : t_pipe 17.6 us vs STREAM 78 us    -> grouped up to 4 groups (96 sequences);
+                with conditioning STREAM does not exist, the alternative is GENERIC
+                (~0.3 ms per step): grouped up to 16 groups;
+      C=K=128 : t_pipe 79 us vs GENERIC 490 us    -> grouped up to 6 groups (24 sequences)."""
+    lib = N.lib()
+    group = max_pipe_batch(dims)
+    if group <= 0 or batch <= group:
+        return "single", N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
+    n_groups = -(-batch // group)
+    if dims.residual_channels == 64:
+        limit = 16 if has_context else 4
+    else:
+        limit = 6
+    if n_groups <= limit:
+        return "grouped", group
+    return "single", N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
+
+
 def max_pipe_batch(dims) -> int:
     """Largest batch one PIPE launch holds co-resident for these dims (0: no PIPE kernel)."""
     lib = N.lib()
@@ -228,7 +271,8 @@ class GroupedGenerator:
     """More sequences than one PIPE launch can hold (24 at config 2): groups of sequences
     take turns on the pipelines, one launch per group per ``advance``.  Per sequence a PIPE
     step costs 17.6 us against 78 us for the STREAM kernel, so three launches of 24 + 24 + 16
-    sequences (53 us per step of all 64) still beat one STREAM launch of 64 (78 us).
+    sequences (53 us per step of all 64) still beat one STREAM launch of 64 (78 us); from
+    five groups on they do not, and ``auto_plan`` picks one STREAM launch instead.
     Same interface as ``RingGenerator``; ``samples`` is one (B, n_total) tensor the groups
     write their row blocks of.  Each group draws from its own Philox key (seed + group)."""
 

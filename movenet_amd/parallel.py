@@ -47,6 +47,8 @@ class FlatGradSync:
         self.world = world if world is not None else (
             dist.get_world_size() if dist.is_initialized() else 1)
         self._flat: Optional[torch.Tensor] = None
+        self.last_path = "none"  # how the last sync_gradients() travelled
+        self.last_floats = 0
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world <= 1:
@@ -88,11 +90,13 @@ class FlatGradSync:
         used = [p for p in self.params if p.grad is not None]
         n = sum(p.grad.numel() for p in used)
         if self.world <= 1 or n == 0:
+            self.last_path, self.last_floats = "none", 0
             return 0
         span = self._contiguous_span(used)
         if span is not None:  # the gradients already lie back to back in one buffer (ops.py)
             dist.all_reduce(span, op=dist.ReduceOp.SUM)
             span.div_(self.world)
+            self.last_path, self.last_floats = "contiguous-span", span.numel()
             return span.numel()
         if self._flat is None or self._flat.numel() != n or self._flat.device != used[0].grad.device:
             self._flat = torch.empty(n, dtype=used[0].grad.dtype, device=used[0].grad.device)
@@ -108,4 +112,5 @@ class FlatGradSync:
             k = p.grad.numel()
             p.grad.copy_(self._flat[off:off + k].view_as(p.grad))
             off += k
+        self.last_path, self.last_floats = "staged-copy", n
         return n

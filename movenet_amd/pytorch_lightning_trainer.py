@@ -223,13 +223,29 @@ class Trainer:
             torch.cuda.synchronize(dev)
             epoch_s = time.perf_counter() - t0
             model.eval()
+            # epoch means of val_loss / val_acc, weighted by batch size and summed over the
+            # ranks' shards: what Lightning's self.log(..., on_epoch=True) reports for
+            # validation_step (pytorch_lightning_trainer.py:91-92), not the last batch's values
+            val_sum = torch.zeros(3, dtype=torch.float64)  # loss * n, acc * n, n
             with torch.no_grad():
                 for batch_idx, batch in enumerate(model.val_dataloader()):
                     if self.limit is not None and batch_idx >= self.limit:
                         break
                     out = model.validation_step(batch, batch_idx)
+                    n = float(out["output"].shape[0])
+                    val_sum += torch.tensor([model.logged["val_loss"] * n, model.logged["val_acc"] * n, n],
+                                            dtype=torch.float64)
                     for cb in self.callbacks:
                         cb.on_validation_batch_end(self, model, out, batch, batch_idx, 0)
+            if world > 1:
+                import torch.distributed as dist
+                t = val_sum.to(dev) if dist.get_backend() == "nccl" else val_sum
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                val_sum = t.cpu()
+            if val_sum[2] > 0:
+                model.logged["val_loss"] = float(val_sum[0] / val_sum[2])
+                model.logged["val_acc"] = float(val_sum[1] / val_sum[2])
+            self.val_epoch_means = {k: v for k, v in model.logged.items() if k.startswith("val")}
             if rank == 0:
                 print(json.dumps({"epoch": epoch, "epoch_seconds": epoch_s,
                                   **{k: v for k, v in model.logged.items() if k.startswith("val")}}),

@@ -24,7 +24,8 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
-from .generation import GroupedGenerator, RingGenerator, _require_gpu, _stream_ptr, max_pipe_batch
+from .generation import (GroupedGenerator, PipeHandoffTimeout, RingGenerator, _require_gpu, _stream_ptr,
+                         auto_plan)
 
 # module constants other movenet files import (movenet/wavenet.py:27-31)
 MAX_AUDIO_FRAMES = 160000
@@ -100,6 +101,7 @@ class WaveNet(nn.Module):
 
         self._dims = N.make_dims(layer_size, stack_size, Q, C, K)
         self._gen_variant = N.GEN_AUTO
+        self.last_generate_fallback = None  # variant a timed-out PIPE call was rerun on
 
     # ---- shape arithmetic (host only) ---------------------------------
     @property
@@ -199,17 +201,34 @@ class WaveNet(nn.Module):
                              f"n_samples={n_total} asked for")
         kw = dict(batch=idx.shape[0], n_total=n_total, device=audio.device,
                   temperature=float(temperature), seed=seed, context=context)
+        def run(variant, group):
+            if group:
+                gen = GroupedGenerator(self.layer_size, self.stack_size, self.input_channels,
+                                       self.residual_channels, self.skip_channels, state,
+                                       group=group, **kw)
+            else:
+                gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
+                                    self.residual_channels, self.skip_channels, state,
+                                    variant=variant, **kw)
+            gen.prime(idx[:, :rf])
+            gen.advance(n_total - rf)
+            gen.check_errors()  # synchronises; never hand unchecked samples on
+            return gen
+
         with torch.cuda.device(audio.device):
-            group = max_pipe_batch(self._dims) if self._gen_variant == N.GEN_AUTO else 0
-        if 0 < group < idx.shape[0]:
-            # more sequences than one pipelined launch holds: groups take turns (still faster
-            # per sequence than the weight-streaming kernel)
-            gen = GroupedGenerator(self.layer_size, self.stack_size, self.input_channels,
-                                   self.residual_channels, self.skip_channels, state, group=group, **kw)
-        else:
-            gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
-                                self.residual_channels, self.skip_channels, state,
-                                variant=self._gen_variant, **kw)
-        gen.prime(idx[:, :rf])
-        gen.advance(n_total - rf)
+            if self._gen_variant == N.GEN_AUTO:
+                kind, what = auto_plan(self._dims, idx.shape[0], context is not None)
+            else:
+                kind, what = "single", self._gen_variant
+        try:
+            gen = run(what, 0) if kind == "single" else run(N.GEN_PIPE, what)
+        except PipeHandoffTimeout:
+            # the pipelined kernel needs all its stages co-resident and something else held
+            # CUs: rerun THIS call (same prompt, same seed) on a kernel without hand-offs
+            with torch.cuda.device(audio.device):
+                lib = N.lib()
+                fallback = N.GEN_STREAM if (context is None and lib.mvn_gen_variant(
+                    self._dims, N.GEN_STREAM, idx.shape[0]) == N.GEN_STREAM) else N.GEN_GENERIC
+            self.last_generate_fallback = fallback
+            gen = run(fallback, 0)
         return self._one_hot_of(gen.samples, audio.dtype)

@@ -283,3 +283,172 @@ def test_integration_stub_runs():
     want = model.generate(prompt, n_samples=rf + 20, temperature=0.0)
     got = ns["fast_generate"](model, prompt, rf + 20, temperature=0.0)
     assert torch.equal(got, want)
+
+
+# ---- temperature > 0 (the reference's DEFAULT, movenet/wavenet.py:200, :227-231) on the
+# kernels config 2 actually runs, and the PIPE status word -------------------------------
+CFG2 = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+
+
+@pytest.mark.parametrize("temperature", [0.5, 1.0])
+def test_sampler_same_draws_on_generic_stream_pipe(temperature):
+    """All three kernels draw with the Philox counter (seed, u, b): on one teacher-forced
+    history (so that a differing draw cannot change later inputs) they must pick the same
+    class on >= 99.9 % of 11 200 draws -- a difference is only possible where the uniform
+    falls within rounding of a CDF edge."""
+    from movenet_amd.utils.weights import make_state_dict
+    sd = make_state_dict(**CFG2, seed=3, gain=2.0, head_gain=6.0)
+    rf, B, n_new = 3072, 16, 700
+    hist = synthetic_indices(B, rf + n_new, 256, 4321).to(DEV)
+    picks = {}
+    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_PIPE):
+        g = _gen(CFG2, sd, B, rf + n_new, variant=variant, temperature=temperature, seed=77)
+        choices, _ = g.teacher_forced(hist, logits_t0=rf)
+        g.check_errors()
+        picks[variant] = choices[:, rf:].cpu().numpy()
+        assert picks[variant].min() >= 0 and picks[variant].max() < 256
+    n = picks[N.GEN_GENERIC].size
+    assert n >= 10000
+    for a, b in ((N.GEN_GENERIC, N.GEN_STREAM), (N.GEN_GENERIC, N.GEN_PIPE), (N.GEN_STREAM, N.GEN_PIPE)):
+        same = (picks[a] == picks[b]).mean()
+        assert same >= 0.999, f"variants {a}/{b} agree on {same:.5f} of {n} draws"
+    # the draws are samples, not the arg-max: many distinct classes, and another seed differs
+    assert len(np.unique(picks[N.GEN_PIPE])) > 32
+    g2 = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_PIPE, temperature=temperature, seed=78)
+    other, _ = g2.teacher_forced(hist, logits_t0=rf)
+    assert (other[:, rf:].cpu().numpy() != picks[N.GEN_PIPE]).mean() > 0.5
+
+
+@pytest.mark.parametrize("variant", [N.GEN_PIPE, N.GEN_STREAM])
+def test_sampler_frequencies_match_oracle_distribution(variant):
+    """32 784 draws of ONE config-2 step (24 identical sequences x 1366 seeds) against the
+    oracle's pre-sampling distribution softmax(softmax(logits) / T) for that step."""
+    from movenet_amd.utils.weights import make_state_dict
+    sd = make_state_dict(**CFG2, seed=3, gain=2.0, head_gain=6.0)
+    dims = O.Dims(**CFG2)
+    rf, B, T = 3072, 24, 0.5
+    pidx = synthetic_indices(1, rf, 256, 555)
+    with torch.no_grad():
+        probs = O.forward(sd, dims, one_hot(pidx, 256), output_unnormalized=True, remove_last=False)
+        p2 = O.pre_sampling_probs(probs, T)[0, :, 0].double().numpy()
+    g = _gen(CFG2, sd, B, rf + 1, variant=variant, temperature=T, seed=0)
+    g.prime(pidx.repeat(B, 1).to(DEV))
+    state0, samples0, t0 = g.state.clone(), g.samples.clone(), g.t
+    draws = []
+    for seed in range(1366):
+        g.state.copy_(state0)
+        g.samples.copy_(samples0)
+        g.t, g.seed = t0, seed
+        g.advance(1)
+        draws.append(g.samples[:, rf].clone())
+    g.check_errors()
+    draws = torch.cat(draws).cpu().numpy()
+    n = draws.size
+    assert n == 24 * 1366
+    freq = np.bincount(draws, minlength=256) / n
+    # per-class standard error sqrt(p (1 - p) / n); allow 6 sigma on every class
+    assert (np.abs(freq - p2) < 6 * np.sqrt(p2 * (1 - p2) / n) + 1e-9).all()
+    assert p2.max() > 2 * p2.min()  # not the near-uniform distribution of unsharpened weights
+
+
+def test_sampler_pipe_chunked_launches_same_as_one_launch():
+    """T = 1.0 free run on PIPE: the draw for (b, u) does not depend on how the steps are
+    partitioned into launches, nor on the queues being primed by the forward kernels."""
+    from movenet_amd.utils.weights import make_state_dict
+    sd = make_state_dict(**CFG2, seed=3, gain=2.0, head_gain=6.0)
+    rf, B, n_new = 3072, 16, 60
+    pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
+    runs = []
+    for chunk in (n_new, 7, 1):
+        g = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_PIPE, temperature=1.0, seed=5)
+        g.prime(pidx)
+        for _ in range(0, n_new, chunk):
+            g.advance(chunk)
+        g.check_errors()
+        runs.append(g.samples.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    s = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_STREAM, temperature=1.0, seed=5)
+    s.prime(pidx)
+    s.advance(n_new)
+    # free-running: one differing draw changes the rest of that sequence, so compare the
+    # first 8 draws of every sequence (the teacher-forced test above covers the long run)
+    assert torch.equal(s.samples[:, :rf + 8], runs[0][:, :rf + 8])
+
+
+def test_pipe_status_word_is_sticky_and_checked():
+    """A raised hand-off status word (here: raised by the test) makes every later launch a
+    no-op until the state is reset, and check_errors() raises: a time-out in one advance()
+    chunk is not erased by the next launch."""
+    from movenet_amd.generation import PipeHandoffTimeout
+    from movenet_amd.utils.weights import make_state_dict
+    sd = make_state_dict(**CFG2, seed=1, gain=2.0, head_gain=6.0)
+    rf, B, n_new = 3072, 4, 16
+    pidx = synthetic_indices(B, rf, 256, 3).to(DEV)
+    g = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_PIPE)
+    g.prime(pidx)
+    g.advance(4)
+    g.check_errors()
+    good = g.samples.clone()
+    g.status_word().fill_(1)
+    g.advance(4)
+    with pytest.raises(PipeHandoffTimeout):
+        g.check_errors()
+    assert torch.equal(g.samples, good)  # the launch did nothing
+    g.advance(4)                          # ... and the word survives the next launch
+    with pytest.raises(PipeHandoffTimeout):
+        g.check_errors()
+    g.prime(pidx)                         # reset() clears it
+    g.advance(n_new)
+    g.check_errors()
+    ref = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_STREAM)
+    ref.prime(pidx)
+    ref.advance(n_new)
+    assert torch.equal(g.samples, ref.samples)
+
+
+def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
+    """WaveNet.generate never returns unchecked samples: with the PIPE status word raised
+    during the call it reruns the same call on STREAM in the same process."""
+    from movenet_amd import generation as G
+    from movenet_amd.utils.weights import make_state_dict
+    from movenet_amd.wavenet import WaveNet
+    sd = make_state_dict(**CFG2, seed=1, gain=2.0, head_gain=6.0)
+    model = WaveNet(**CFG2)
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV)
+    rf, B, n_new = 3072, 3, 20
+    prompt = one_hot(synthetic_indices(B, rf, 256, 8), 256).to(DEV)
+    want = model.generate(prompt, n_samples=rf + n_new, temperature=0.0)
+    assert model.last_generate_fallback is None
+    real_advance, poked = G.RingGenerator.advance, []
+
+    def advance(self, n):
+        if self.variant == N.GEN_PIPE:
+            self.status_word().fill_(1)
+            poked.append(self.variant)
+        return real_advance(self, n)
+
+    monkeypatch.setattr(G.RingGenerator, "advance", advance)
+    got = model.generate(prompt, n_samples=rf + n_new, temperature=0.0)
+    assert poked == [N.GEN_PIPE] and model.last_generate_fallback == N.GEN_STREAM
+    assert torch.equal(got, want)
+    # a variant forced by the caller that cannot be rerun differently still never returns
+    # silently: the generator's own check raises
+    g = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_PIPE)
+    g.prime(synthetic_indices(B, rf, 256, 8).to(DEV))
+    g.advance(n_new)
+    with pytest.raises(G.PipeHandoffTimeout):
+        g.check_errors()
+
+
+def test_auto_plan_cost_based():
+    from movenet_amd.generation import auto_plan
+    d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
+    assert auto_plan(d2, 16, False) == ("single", N.GEN_PIPE)
+    assert auto_plan(d2, 64, False) == ("grouped", 24)
+    assert auto_plan(d2, 96, False) == ("grouped", 24)
+    assert auto_plan(d2, 97, False) == ("single", N.GEN_STREAM)   # 5 x 17.6 us > 78 us
+    assert auto_plan(d2, 256, True) == ("grouped", 24)            # no conditioned STREAM kernel
+    assert auto_plan(d5, 4, False) == ("single", N.GEN_PIPE)
+    assert auto_plan(d5, 24, False) == ("grouped", 4)
+    assert auto_plan(d5, 25, False) == ("single", N.GEN_GENERIC)
