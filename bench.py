@@ -164,14 +164,15 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
     forward (probabilities), cross_entropy on them (Q2), backward through the HIP
     kernels, one flat gradient all-reduce when world > 1, AdamW.  Token = one
     (sequence, time) position with a target: B * (T - RF)."""
-    from movenet_amd.ops import cross_entropy_on_probs
+    from movenet_amd.ops import wavenet_forward_loss
+    from movenet_amd.optim import FlatAdamW, order_like_backward
     from movenet_amd.parallel import FlatGradSync
     from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices
     from movenet_amd.wavenet import WaveNet
     model = WaveNet(**CFG)
     model.load_state_dict(make_state_dict(**CFG, seed=0))
     model.to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    opt = FlatAdamW(order_like_backward(model), lr=1e-4)  # torch.optim.AdamW's rule, one kernel
     sync = FlatGradSync(model.parameters(), world)
     sync.broadcast_parameters(0)
     Q, rf = CFG["input_channels"], 3072
@@ -180,7 +181,7 @@ def train_leg(dev, world, rank, steps=4, warmup=2, batch=16, t_len=16000):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _ = cross_entropy_on_probs(model(audio), target)  # the trainer's fused loss + accuracy
+        loss, _, _ = wavenet_forward_loss(model, audio, None, target)  # the trainer's fused step
         loss.backward()
         sync.sync_gradients()
         opt.step()

@@ -229,7 +229,10 @@ typedef struct mvn_bwd_buffers {
 } mvn_bwd_buffers;
 
 /* dout: gradient w.r.t. mvn_forward's `out` (same shape); `out` itself is needed
- * when normalize != 0 (softmax backward).  Requires the forward ran with save.
+ * when normalize != 0 (softmax backward).  dout == NULL: the caller has already written the
+ * gradient w.r.t. the LOGITS into bwd->dlogit (layout (B, Q, Sp), the column of output
+ * position s is s + ((RF-1) & 3), columns of positions >= S_out zero) -- what
+ * mvn_softmax_ce_backward does.  Requires the forward ran with save.
  * Part of the work is enqueued on a stream the library owns (one per device) and joined
  * back into `stream` with events before the call returns: to the caller it is ordinary
  * stream-ordered work.  da1 / dlogit / dfg double as scratch of the weight gradients. */
@@ -300,6 +303,29 @@ int mvn_ce_on_probs_forward(const float *probs, const long long *target, int bat
 int mvn_ce_on_probs_backward(const float *probs, const long long *target, int batch, int classes,
                              int s_len, float scale, const float *upstream, float *dprobs,
                              void *stream);
+
+/* The same loss and accuracy FUSED with the model's final softmax (wavenet.py:189-191):
+ * forward turns the head's logits (B, Q, S) into probabilities IN PLACE and accumulates the
+ * loss / accuracy partial sums of mvn_ce_on_probs_forward in the same pass (same slots, same
+ * bits); backward writes d loss / d logits -- through cross_entropy's log-softmax AND the
+ * model's softmax -- into a (B, Q, dlogit_ld) tensor at columns dlogit_col0 .. +dlogit_cols
+ * (zero for the dlogit_cols - s_len trailing columns), i.e. straight into mvn_backward's
+ * dlogit buffer (call mvn_backward with dout = NULL). */
+int mvn_softmax_ce_forward(float *logits_probs, const long long *target, int batch, int classes,
+                           int s_len, float *loss_part, int32_t *correct_part, void *stream);
+int mvn_softmax_ce_backward(const float *probs, const long long *target, int batch, int classes,
+                            int s_len, float scale, const float *upstream, float *dlogit,
+                            long long dlogit_batch_stride, int dlogit_ld, int dlogit_col0,
+                            int dlogit_cols, void *stream);
+
+/* One optimizer step of torch.optim.AdamW (decoupled != 0) or torch.optim.Adam (decoupled == 0,
+ * weight decay added to the gradient) over flat fp32 buffers of n elements
+ * (movenet/pytorch_lightning_trainer.py:186-189; arithmetic of torch's _single_tensor_adam,
+ * amsgrad off).  step counts from 1.  skip_ranges: HOST array of n_skip <= 4 [lo, hi) element
+ * ranges left untouched (parameters without a gradient this step). */
+int mvn_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   int decoupled, const size_t *skip_ranges, int n_skip, void *stream);
 
 /* mu-law companding either side of the model (movenet/dataset.py:278-289 encode ->
  * one-hot; movenet/callbacks.py:66-76 argmax -> decode).  The reference calls torchaudio,

@@ -128,6 +128,14 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p]),
     "mvn_ce_on_probs_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mvn_softmax_ce_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "mvn_softmax_ce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]),
+    "mvn_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                 C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "mvn_mu_law_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "mvn_mu_law_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "mvn_onehot_to_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

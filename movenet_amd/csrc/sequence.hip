@@ -892,7 +892,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   }
   if (!p || !gr || !fwd || !bwd || !fwd->acts || !fwd->th || !fwd->sg || !fwd->skip ||
       !fwd->a1 || !bwd->dx_a || !bwd->dx_b || !bwd->dfg || !bwd->dskip || !bwd->da1 ||
-      !bwd->dlogit || !dout || (normalize && !out)) {
+      !bwd->dlogit || (dout && normalize && !out)) {
     set_error("mvn_backward: NULL buffer");
     return MVN_ERR_BAD_ARG;
   }
@@ -941,7 +941,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
-  if (normalize && Q <= 4 * CQ)
+  if (!dout) {
+    // the caller has filled bwd->dlogit itself (mvn_softmax_ce_backward: the trainer's loss and
+    // the model's softmax differentiated in one pass)
+  } else if (normalize && Q <= 4 * CQ)
     hipLaunchKernelGGL(softmax_bwd_cols_kernel, dim3((g.S + 63) / 64, batch), dim3(256), 0, s, out, dout,
                        dlog, Q, S_out, g.S, g.pad);
   else

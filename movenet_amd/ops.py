@@ -119,56 +119,128 @@ class _WaveNetFunction(torch.autograd.Function):
     def backward(ctx_, dout):
         if not ctx_.saved_fwd:
             raise RuntimeError("movenet_amd: forward ran without saved activations")
-        lib = N.lib()
         out, *params = ctx_.saved_tensors
-        dims, names, idx, buf = ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf
-        L = dims.layer_size * dims.stack_size
-        C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
-        dense_in = idx.dim() == 3
-        B, T = (idx.shape[0], idx.shape[2]) if dense_in else idx.shape
-        dev = idx.device
-        sd = dict(zip(names, params))
         dout = dout.to(torch.float32).contiguous()
-        with torch.cuda.device(dev):
-            # one zero-filled flat buffer, the per-parameter gradients are views into it (one
-            # fill kernel instead of ~190; FlatGradSync all-reduces the buffer in place)
-            sizes = [p.numel() for p in params]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-            grads, off = {}, 0
-            for n, p_, k in zip(names, params, sizes):
-                grads[n] = flat[off:off + k].view(p_.shape)
-                off += k
-            gp, gkeep = pack_params(dims, grads, L)
-            g = N.ParamGrads(gp.causal_w, gp.filter_w, gp.gate_w, gp.residual_w, gp.residual_b,
-                             gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b,
-                             gp.ctx_filter_w, gp.ctx_filter_b, gp.ctx_gate_w, gp.ctx_gate_b)
-            f32 = dict(dtype=torch.float32, device=dev)
-            dx_a = torch.empty((B, C, buf.Tp), **f32)
-            dx_b = torch.empty((B, C, buf.Tp), **f32)
-            dfg = torch.empty((B, 2 * C, buf.Tp), **f32)
-            dskip = torch.empty((B, K, buf.Sp), **f32)
-            da1 = torch.empty((B, Q, buf.Sp), **f32)
-            dlogit = torch.empty((B, Q, buf.Sp), **f32)
-            dctx = torch.empty((B, C, buf.Tp), **f32) if ctx_.has_context else None
-            bw = N.BwdBuffers(dx_a.data_ptr(), dx_b.data_ptr(), dfg.data_ptr(), dskip.data_ptr(),
-                              da1.data_ptr(), dlogit.data_ptr(),
-                              None if dctx is None else dctx.data_ptr())
-            params_c, pkeep = pack_params(dims, sd, L)
-            N.check(lib.mvn_backward(dims, params_c, g, None if dense_in else idx.data_ptr(),
-                                     0 if dense_in else idx.stride(0), B, T,
-                                     buf.struct, bw, out.data_ptr(), dout.data_ptr(),
-                                     int(ctx_.normalize), int(ctx_.remove_last), _stream_ptr(dev)),
-                    "mvn_backward")
-        # (buffers are released with the autograd node; a retained graph may run backward again)
-        last = f"residual_conv_stack.conv_layers.{L - 1}.conv_residual."
-        need = ctx_.needs_input_grad
-        result = []
-        for n, want in zip(names, need[_WaveNetFunction.N_FIXED:]):
-            # the last layer's residual conv never reaches the output: the
-            # reference leaves its .grad None, so do we
-            result.append(None if (n.startswith(last) or not want) else grads[n])
-        dcontext = dctx[:, :, :T] if (ctx_.has_context and need[5]) else None
-        return (None, None, None, None, None, dcontext, *result)
+        grads, dctx = _run_backward(ctx_, params, out, dout, None)
+        return _grads_for_autograd(ctx_, grads, dctx, _WaveNetFunction.N_FIXED, ctx_.needs_input_grad)
+
+
+def _run_backward(ctx_, params, out, dout, fill_dlogit):
+    """mvn_backward for a saved forward.  ``dout``: gradient w.r.t. the model output, or None
+    when ``fill_dlogit(dlogit, Sp, pad)`` writes the gradient w.r.t. the logits itself (the
+    fused loss).  Returns ({name: grad view into ONE flat buffer}, dctx or None)."""
+    lib = N.lib()
+    dims, names, idx, buf = ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf
+    L = dims.layer_size * dims.stack_size
+    C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
+    dense_in = idx.dim() == 3
+    B, T = (idx.shape[0], idx.shape[2]) if dense_in else idx.shape
+    dev = idx.device
+    sd = dict(zip(names, params))
+    with torch.cuda.device(dev):
+        # one zero-filled flat buffer, the per-parameter gradients are views into it (one
+        # fill kernel instead of ~190; FlatGradSync all-reduces the buffer in place and
+        # FlatAdamW steps over it with one kernel)
+        sizes = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        grads, off = {}, 0
+        for n, p_, k in zip(names, params, sizes):
+            grads[n] = flat[off:off + k].view(p_.shape)
+            off += k
+        gp, gkeep = pack_params(dims, grads, L)
+        g = N.ParamGrads(gp.causal_w, gp.filter_w, gp.gate_w, gp.residual_w, gp.residual_b,
+                         gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b,
+                         gp.ctx_filter_w, gp.ctx_filter_b, gp.ctx_gate_w, gp.ctx_gate_b)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dx_a = torch.empty((B, C, buf.Tp), **f32)
+        dx_b = torch.empty((B, C, buf.Tp), **f32)
+        dfg = torch.empty((B, 2 * C, buf.Tp), **f32)
+        dskip = torch.empty((B, K, buf.Sp), **f32)
+        da1 = torch.empty((B, Q, buf.Sp), **f32)
+        dlogit = torch.empty((B, Q, buf.Sp), **f32)
+        dctx = torch.empty((B, C, buf.Tp), **f32) if ctx_.has_context else None
+        bw = N.BwdBuffers(dx_a.data_ptr(), dx_b.data_ptr(), dfg.data_ptr(), dskip.data_ptr(),
+                          da1.data_ptr(), dlogit.data_ptr(),
+                          None if dctx is None else dctx.data_ptr())
+        if fill_dlogit is not None:
+            rf = N.check(lib.mvn_receptive_fields(dims), "mvn_receptive_fields")
+            fill_dlogit(dlogit, buf.Sp, (rf - 1) & 3)
+        params_c, pkeep = pack_params(dims, sd, L)
+        N.check(lib.mvn_backward(dims, params_c, g, None if dense_in else idx.data_ptr(),
+                                 0 if dense_in else idx.stride(0), B, T,
+                                 buf.struct, bw, None if out is None else out.data_ptr(),
+                                 None if dout is None else dout.data_ptr(),
+                                 int(ctx_.normalize), int(ctx_.remove_last), _stream_ptr(dev)),
+                "mvn_backward")
+    # (buffers are released with the autograd node; a retained graph may run backward again)
+    return grads, (dctx[:, :, :T] if dctx is not None else None)
+
+
+def _grads_for_autograd(ctx_, grads, dctx, n_fixed, need):
+    dims, names = ctx_.dims, ctx_.names
+    L = dims.layer_size * dims.stack_size
+    last = f"residual_conv_stack.conv_layers.{L - 1}.conv_residual."
+    result = []
+    for n, want in zip(names, need[n_fixed:]):
+        # the last layer's residual conv never reaches the output: the
+        # reference leaves its .grad None (SURVEY.md 2.2 C3), so do we
+        result.append(None if (n.startswith(last) or not want) else grads[n])
+    dcontext = dctx if (ctx_.has_context and need[n_fixed - 1]) else None
+    return (*([None] * (n_fixed - 1)), dcontext, *result)
+
+
+class _WaveNetLossFunction(torch.autograd.Function):
+    """Forward + the trainer's loss in one autograd node (row F3): the head's logits become
+    probabilities and the loss / accuracy partial sums in ONE pass (mvn_softmax_ce_forward);
+    backward differentiates loss -> logits in ONE pass (mvn_softmax_ce_backward) straight into
+    mvn_backward's dlogit buffer.  args: dims, names, idx, target (B,S) int64, ctx, *params;
+    returns (loss, accuracy, probs)."""
+    N_FIXED = 5
+
+    @staticmethod
+    def forward(ctx_, dims, names, idx, target, context, *params):
+        lib = N.lib()
+        sd = dict(zip(names, params))
+        save = any(ctx_.needs_input_grad[4:])
+        out, buf = run_forward(dims, sd, idx, False, True, save, context)  # logits, last column dropped
+        B, Q, S = out.shape
+        if target.shape != (B, S):
+            raise ValueError(f"target must be (batch, {S}), got {tuple(target.shape)}")
+        tg = target.detach().to(device=out.device, dtype=torch.int64).contiguous()
+        with torch.cuda.device(out.device):
+            parts = max(lib.mvn_ce_parts(B, S), 1)
+            loss_part = torch.zeros(parts, dtype=torch.float32, device=out.device)
+            ok_part = torch.zeros(parts, dtype=torch.int32, device=out.device)
+            N.check(lib.mvn_softmax_ce_forward(out.data_ptr(), tg.data_ptr(), B, Q, S, loss_part.data_ptr(),
+                                               ok_part.data_ptr(), _stream_ptr(out.device)),
+                    "mvn_softmax_ce_forward")
+        n = max(B * S, 1)
+        loss = loss_part.sum() / n
+        acc = ok_part.sum().to(torch.float32) / n
+        ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf = dims, names, idx, buf
+        ctx_.normalize, ctx_.remove_last, ctx_.saved_fwd = True, True, save
+        ctx_.has_context = context is not None
+        ctx_.save_for_backward(out, tg, *params)
+        ctx_.mark_non_differentiable(acc, out)
+        return loss, acc, out
+
+    @staticmethod
+    def backward(ctx_, dloss, _dacc, _dprobs):
+        if not ctx_.saved_fwd:
+            raise RuntimeError("movenet_amd: forward ran without saved activations")
+        lib = N.lib()
+        probs, tg, *params = ctx_.saved_tensors
+        B, Q, S = probs.shape
+        up = dloss.detach().to(device=probs.device, dtype=torch.float32).reshape(1).contiguous()
+
+        def fill(dlogit, Sp, pad):
+            N.check(lib.mvn_softmax_ce_backward(
+                probs.data_ptr(), tg.data_ptr(), B, Q, S, 1.0 / max(B * S, 1), up.data_ptr(),
+                dlogit.data_ptr(), Q * Sp, Sp, pad, S + 1, _stream_ptr(probs.device)),
+                "mvn_softmax_ce_backward")
+
+        grads, dctx = _run_backward(ctx_, params, None, None, fill)
+        return _grads_for_autograd(ctx_, grads, dctx, _WaveNetLossFunction.N_FIXED, ctx_.needs_input_grad)
 
 
 class _UpsampleVideoFunction(torch.autograd.Function):
@@ -248,6 +320,30 @@ def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalize
     out = _WaveNetFunction.apply(model._dims, names, idx, bool(output_unnormalized),
                                  bool(remove_last), context, *params)
     return out if audio.dtype == torch.float32 else out.to(audio.dtype)
+
+
+def wavenet_forward_loss(model, audio: torch.Tensor, context=None, target=None):
+    """(loss, accuracy, probabilities) of one trainer step in one autograd node:
+    ``output = model(audio, video)`` (probabilities, Q1), ``target =
+    audio[:, :, RF:].argmax(1)``, ``F.cross_entropy(output, target)`` (on probabilities, Q2) and
+    the accuracy -- movenet/pytorch_lightning_trainer.py:62-66 -- with the softmax, the loss and
+    the accuracy fused into one pass over the head's logits and their gradients into one pass
+    back.  Same values as ``cross_entropy_on_probs(wavenet_forward(...), target)``."""
+    idx = model._indices_of(audio, strict=False)
+    rf = model.receptive_fields
+    if target is None:
+        if idx is None:
+            target = audio[:, :, rf:].argmax(1)
+        else:
+            target = idx[:, rf:].to(torch.int64)
+    if idx is None:
+        idx = audio.detach().to(torch.float32).contiguous()
+    model.compute_output_size(audio)
+    L = model.layer_size * model.stack_size
+    names = decoder_param_names(L, with_context=context is not None)
+    lookup = dict(model.named_parameters())
+    params = [lookup[n] for n in names]
+    return _WaveNetLossFunction.apply(model._dims, names, idx, target, context, *params)
 
 
 def mu_law_encode(x: torch.Tensor, quantization_channels: int) -> torch.Tensor:
