@@ -101,6 +101,13 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
                           registers/LDS, activations handed on as 8-byte granules;
                           needs all stages co-resident, at most 32 per XCD         */
 
+#define MVN_GEN_PIPE_F16 4 /* C=K=128, Q=256: the PIPE structure with FP16 OPERANDS and FP32
+                              ACCUMULATION (BASELINE configs[4]; precedent: torch.autocast,
+                              movenet/trainer.py:124): weights and every product's vector
+                              operand rounded to fp16, v_dot2c_f32_f16 sums in fp32; two layers
+                              per stage, ceil(L/2)+1 stages (31 for 60 layers: one XCD).  Never
+                              chosen by MVN_GEN_AUTO: fp32 is the default precision.            */
+
 /* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
  * variant or a negative error.  The packed weight layout depends on the variant:
  * pack and generate must be given the same resolved value. */

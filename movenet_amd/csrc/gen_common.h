@@ -67,4 +67,13 @@ int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t
 int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s);
 int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s);
 
+
+// ---- PIPE variant with fp16 operands (generate_pipe_h16.hip), C = K = 128 ----------------
+bool pipe_h16_ok(const mvn_dims *d);
+int pipe_h16_stages(const mvn_dims *d);
+int pipe_h16_max_batch(const mvn_dims *d);
+size_t pipe_h16_weights_floats(const mvn_dims *d);  // packed blob without the context section
+int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool has_ctx, hipStream_t s);
+int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s);
+
 }  // namespace mvn

@@ -651,6 +651,7 @@ static size_t gen_base_floats(const mvn_dims *dims, int variant) {
   const size_t C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const size_t L = n_layers(dims);
   if (variant == MVN_GEN_PIPE) return pipe_weights_floats(dims);
+  if (variant == MVN_GEN_PIPE_F16) return pipe_h16_weights_floats(dims);
   if (variant == MVN_GEN_STREAM) return s64::EMB_FLOATS + 4 * (L * s64::LAYER_F4 + s64::HEAD_F4);
   return 2 * Q * C + L * (4 * C * C + C * (C + K) + (C + K)) + K * Q + Q + Q * Q + Q;
 }
@@ -736,6 +737,15 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
     }
     return MVN_GEN_PIPE;
   }
+  if (requested == MVN_GEN_PIPE_F16) {
+    if (!mvn::pipe_h16_ok(dims) || batch < 1 || device_cus() < 256 || batch > mvn::pipe_h16_max_batch(dims)) {
+      mvn::set_error("PIPE_F16 variant needs C=K=128, Q=256, 256 CUs and batch <= %d for these dims "
+                     "(ceil(L/2)+1 stages per sequence, 32 per XCD)",
+                     mvn::pipe_h16_ok(dims) ? mvn::pipe_h16_max_batch(dims) : 0);
+      return MVN_ERR_UNSUPPORTED;
+    }
+    return MVN_GEN_PIPE_F16;
+  }
   if (requested == MVN_GEN_STREAM) {
     if (!mvn::stream_ok(dims)) {
       mvn::set_error("STREAM variant needs C=K=64, Q=256, <=80 layers");
@@ -800,6 +810,7 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
     if (rc || !has_ctx) return rc;
     return mvn::pipe_pack_ctx(dims, p, ctx_section, stream);
   }
+  if (variant == MVN_GEN_PIPE_F16) return mvn::pipe_h16_pack(dims, p, packed, has_ctx, stream);
   if (has_ctx && variant == MVN_GEN_GENERIC) {
     const int Cc = dims->residual_channels, n = 2 * Cc * Cc + 2 * Cc;
     for (int l = 0; l < mvn::n_layers(dims); ++l)
@@ -887,6 +898,10 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
   if (variant == MVN_GEN_PIPE) {
     float *hand = state + (size_t)batch * a.state_per_seq;
     return mvn::pipe_launch(a, dims, batch, hand, (hipStream_t)stream);
+  }
+  if (variant == MVN_GEN_PIPE_F16) {
+    float *hand = state + (size_t)batch * a.state_per_seq;
+    return mvn::pipe_h16_launch(a, dims, batch, hand, (hipStream_t)stream);
   }
   if (variant == MVN_GEN_STREAM) {
     const size_t lds =

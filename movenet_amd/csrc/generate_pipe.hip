@@ -24,16 +24,13 @@
 
 #include "common.h"
 #include "gen_common.h"
+#include "pipe_common.h"
 
 namespace mvn {
-
-typedef unsigned long long u64;
-typedef float4 f4;
 
 // Shape traits.  C = K = 64: 4 layers per stage, a thread owns 2 rows x 16 inputs (4 lanes
 // per channel).  C = K = 128 (BASELINE config 5): the 3 x 128 KB of a single layer already
 // fill a CU, so 1 layer per stage, 2 rows x 64 inputs per thread (2 lanes per channel).
-constexpr int PIPE_XCD_CUS = 32;  // CUs per XCD: one workgroup (133 KB of LDS) per CU
 template <int CC>
 struct PipeCfg {
   static constexpr int C = CC, Q = 256, NT = 512;
@@ -54,139 +51,6 @@ struct PipeCfg {
   // (32768 either way) + a0[C] + a1[Q] + logits[Q]; + 16 flag words
   static constexpr int LDS_FLOATS = 32768 + 8 * CC + 2 * Q + 64 + 16;
 };
-constexpr unsigned PIPE_SPIN_LIMIT = 1u << 23;
-constexpr int PIPE_MAX_GRAN = 256;
-
-#ifdef MVN_PIPE_STAMPS
-// Diagnostic build only (python -m movenet_amd.csrc.build --stamps): wall-clock
-// (s_memrealtime, 100 MHz) stamps of "inbox complete" and "outbox sent" per stage
-// for the first 64 steps of a launch; read back with mvn_debug_read_stamps().
-__device__ unsigned long long g_stamps[16][16][64][4];
-#define MVN_STAMP(bb, ss, step, which)                                              \
-  do {                                                                              \
-    if ((bb) < 16 && (ss) < 16 && (step) < 64 && threadIdx.x == 0) {                \
-      g_stamps[bb][ss][step][which] = __builtin_amdgcn_s_memrealtime();             \
-      g_stamps[bb][ss][step][2 + (which)] = __builtin_amdgcn_s_memtime();           \
-    }                                                                               \
-  } while (0)
-// finer shader-clock stamps inside the first layer of a stage (thread `who`)
-__device__ unsigned long long g_fine[16][16][64][8];
-#define MVN_FINE(bb, ss, step, slot, who)                                           \
-  do {                                                                              \
-    if ((bb) < 16 && (ss) < 16 && (step) < 64 && threadIdx.x == (who))              \
-      g_fine[bb][ss][step][slot] = __builtin_amdgcn_s_memtime();                    \
-  } while (0)
-#else
-#define MVN_STAMP(bb, ss, step, which) do {} while (0)
-#define MVN_FINE(bb, ss, step, slot, who) do {} while (0)
-#endif
-
-// `same_xcd`: producer and consumer were FOUND (from HW_REG_XCC_ID, exchanged at kernel
-// start) to sit on one XCD.  They then share one L2, so a plain store (write-through L1,
-// line kept in that L2) is seen by the consumer's L1-bypassing polls: ~0.33 us per hop
-// instead of ~0.6.  Otherwise the granule is stored sc1 (write-through to memory), the
-// placement-independent form.  Placement only ever selects between two correct forms.
-__device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v, bool same_xcd) {
-  const u64 x = ((u64)epoch << 32) | (u64)__float_as_uint(v);
-  // same XCD: a relaxed WORKGROUP-scope atomic store -- on gfx950 the same write-through
-  // global_store_dwordx2 as a plain store (line kept in the shared L2), but an atomic in the
-  // memory model: never deferred, merged or torn by the compiler
-  if (same_xcd)
-    __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else
-    __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Wave 0 only.  One 16-byte load fetches two granules, and the 64 lanes of a load cover
-// 1 KB of the inbox contiguously: lane i owns granules 128*k + 2*i and 128*k + 2*i + 1 for
-// k < GL/2 (v[2k], v[2k+1]).  Each granule is still validated by its own epoch word; a
-// 16-byte aligned load never tears an 8-byte store.  Returns false on time-out / raised
-// error word (wave-uniform).
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-template <int GL>
-__device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsigned *err,
-                                           float (&v)[GL]) {
-  static_assert(GL == 2 || GL == 4, "one or two 16-byte loads per lane");
-  const int lane = threadIdx.x & 63;
-  const u64 *p = in + 2 * lane;
-  for (unsigned spins = 1;; ++spins) {
-    v4u g0, g1 = {0u, epoch, 0u, epoch};
-    if (GL == 2)
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(g0) : "v"(p) : "memory");
-    else
-      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                   "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(g0), "=&v"(g1) : "v"(p) : "memory");
-    const bool ok = g0.y == epoch && g0.w == epoch && g1.y == epoch && g1.w == epoch;
-    if (__all(ok)) {
-      v[0] = __uint_as_float(g0.x);
-      v[1] = __uint_as_float(g0.z);
-      if (GL == 4) {
-        v[GL - 2] = __uint_as_float(g1.x);
-        v[GL - 1] = __uint_as_float(g1.z);
-      }
-      return true;
-    }
-    if ((spins & 255u) == 0) {
-      const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-// ---- cross-lane moves as DPP (one VALU op) instead of ds_bpermute (an LDS round trip)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each group of 8
-constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each row of 16
-
-// sum over each aligned group of 4 lanes, result in all 4
-__device__ __forceinline__ float quad_sum(float v) {
-  v += dpp_mov<DPP_XOR1>(v);
-  v += dpp_mov<DPP_XOR2>(v);
-  return v;
-}
-// after quad_sum: the value held by the OTHER quad of the same group of 8
-__device__ __forceinline__ float other_quad(float v) { return dpp_mov<DPP_HALF_MIRROR>(v); }
-
-__device__ __forceinline__ float lane_value(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v = quad_sum(v);
-  v += dpp_mov<DPP_HALF_MIRROR>(v);
-  v += dpp_mov<DPP_MIRROR>(v);  // every lane of a row of 16 now holds the row sum
-  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-  v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
-  v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
-  v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
-  v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
-  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
-}
-
-// tanh(f) * sigmoid(g) from two v_exp_f32 and one reciprocal-based division:
-//   tanh(f) = (1 - e^-2|f|) / (1 + e^-2|f|) * sign(f),  sigmoid(g) = 1 / (1 + e^-g)
-// Absolute error ~1e-7 (fp32 rounding of an O(1) value); ~12 VALU ops vs ~100 for
-// the libm forms, and this sits on the per-layer critical path.
-__device__ __forceinline__ float gate_fast(float f, float g) {
-  const float a = __expf(-2.0f * fabsf(f));       // in (0, 1]
-  const float e = __expf(-g);                      // may overflow to +inf: 1/inf = 0 is right
-  const float num = copysignf(1.0f - a, f);
-  const float den = (1.0f + a) * (1.0f + e);
-  return num * __builtin_amdgcn_rcpf(den);  // v_rcp_f32: 1 ulp
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef MVN_EXP
 #define MVN_EXP 0   // timing experiments of scripts/pipe_stamps.py; 0 = the product
@@ -291,18 +155,6 @@ __device__ __forceinline__ float chan_sum(float v) {
   v += dpp_mov<DPP_XOR1>(v);
   if (KQ == 4) v += dpp_mov<DPP_XOR2>(v);
   return v;
-}
-
-// (value, index) arg-max combine: larger value wins, smaller index on ties
-__device__ __forceinline__ void argmax_take(float &bv, int &bi, float ov, int oi) {
-  if (ov > bv || (ov == bv && oi < bi)) {
-    bv = ov;
-    bi = oi;
-  }
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_movi(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
 // Workgroup = 8 waves.  Waves 0-3 ("FG group") own the filter/gate matrices, waves
@@ -656,72 +508,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           if (a.logits_out && u >= a.logits_t0)
             ((f4 *)(a.logits_out +
                     ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
-          const float m = wave_max_dpp(fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3])));
-          float e[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) e[k] = __expf(lg[k] - m);
-          const float sm = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
-          // v_exp_f32 / v_rcp_f32 forms (1-2 ulp): the choice depends on the ORDER of
-          // the probabilities, which these monotone maps preserve
-          const float rs = __builtin_amdgcn_rcpf(sm) *
-                           (a.temperature > 0.f ? __builtin_amdgcn_rcpf(a.temperature) : 1.0f);
-          float p[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) p[k] = e[k] * rs;
-          const float m2 = wave_max_dpp(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) e[k] = __expf(p[k] - m2);
-          const float s2sum = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
-          const float rs2 = __builtin_amdgcn_rcpf(s2sum);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) p[k] = e[k] * rs2;  // the distribution generate() uses
-
-          int pick;
-          if (a.temperature > 0.f) {
-            const float lsum = (p[0] + p[1]) + (p[2] + p[3]);
-            float incl = lsum;  // inclusive scan of lane totals, class order
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-              const float n = __shfl_up(incl, off, 64);
-              if (lane >= off) incl += n;
-            }
-            const float total = lane_value(incl, 63);
-            const float target = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b) * total;
-            const float cdf = incl - lsum;
-            int cand = Q - 1;
-#pragma unroll
-            for (int k = 3; k >= 0; --k) {
-              // walk down so that the smallest qualifying class wins
-              const float c_k = cdf + (k == 0 ? p[0] : k == 1 ? p[0] + p[1]
-                                                      : k == 2 ? (p[0] + p[1]) + p[2]
-                                                               : ((p[0] + p[1]) + p[2]) + p[3]);
-              if (c_k > target) cand = 4 * lane + k;
-            }
-            cand = min(cand, dpp_movi<DPP_XOR1>(cand));
-            cand = min(cand, dpp_movi<DPP_XOR2>(cand));
-            cand = min(cand, dpp_movi<DPP_HALF_MIRROR>(cand));
-            cand = min(cand, dpp_movi<DPP_MIRROR>(cand));
-            pick = min(min(__builtin_amdgcn_readlane(cand, 0), __builtin_amdgcn_readlane(cand, 16)),
-                       min(__builtin_amdgcn_readlane(cand, 32), __builtin_amdgcn_readlane(cand, 48)));
-          } else {
-            float bv = p[0];
-            int bi = 4 * lane;
-#pragma unroll
-            for (int k = 1; k < 4; ++k)
-              if (p[k] > bv) {  // strict: first maximum
-                bv = p[k];
-                bi = 4 * lane + k;
-              }
-            argmax_take(bv, bi, dpp_mov<DPP_XOR1>(bv), dpp_movi<DPP_XOR1>(bi));
-            argmax_take(bv, bi, dpp_mov<DPP_XOR2>(bv), dpp_movi<DPP_XOR2>(bi));
-            argmax_take(bv, bi, dpp_mov<DPP_HALF_MIRROR>(bv), dpp_movi<DPP_HALF_MIRROR>(bi));
-            argmax_take(bv, bi, dpp_mov<DPP_MIRROR>(bv), dpp_movi<DPP_MIRROR>(bi));
-            float rv = lane_value(bv, 0);
-            pick = __builtin_amdgcn_readlane(bi, 0);
-#pragma unroll
-            for (int row = 16; row < 64; row += 16)
-              argmax_take(rv, pick, lane_value(bv, row), __builtin_amdgcn_readlane(bi, row));
-          }
+          const int pick = choose_class(lg, a.temperature, a.seed, (uint32_t)u, (uint32_t)b, lane, Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
           idx_cur = next_idx;

@@ -1,0 +1,579 @@
+// PIPE generator with FP16 OPERANDS and FP32 ACCUMULATION, C = K = 128, Q = 256: the form
+// BASELINE configs[4] names ("60-layer WaveNet, residual_ch=128, fp16 ... 1x1 convs,
+// autoregressive generate of 1 s audio, LDS ring-buffer stress").  Reference precedent for
+// reduced precision: torch.autocast in movenet/trainer.py:124; arithmetic restated:
+// movenet/wavenet.py:217-237, movenet/modules.py:19-30, :67-93, :139-142 (see generate.hip).
+//
+// Same structure as gen_pipe_kernel<128> (generate_pipe.hip): a private pipeline of
+// workgroups per sequence, weights resident, activations handed on as {value, epoch}
+// granules.  What changes with 16-bit operands:
+//   * every weight matrix is stored as halves (rounded to nearest even once, at pack time):
+//     a thread's two rows x 64 inputs are 64 VGPRs instead of 128, a layer's past-tap matrix
+//     64 KB of LDS instead of 128 -- so a stage holds TWO layers and 60 layers are 30 + 1
+//     stages, which fit ONE XCD (fp32: 61 stages over two XCDs);
+//   * the vector operand of every product (residual stream, popped queue entry, context
+//     column, gated activation, head activations) is rounded to fp16 when it is written to
+//     LDS, and a lane reads its 64 inputs with 8 ds_read_b128 instead of 16;
+//   * products and sums run in v_dot2c_f32_f16: fp16 x fp16 products accumulated in fp32.
+// Everything else stays fp32: the residual stream itself, the skip sum, the past-tap
+// partial sums, biases, gating, the embedding rows (a gather, no product), the dilation
+// queues in HBM/L2, logits and the double softmax.
+// Tolerance against the fp32 path: DESIGN.md section 2 / tests/test_fp16_gpu.py.
+#include <cstdlib>
+
+#include "common.h"
+#include "gen_common.h"
+#include "pipe_common.h"
+
+namespace mvn {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));  // 16 bytes
+
+namespace h16 {
+constexpr int C = 128, Q = 256, NT = 512;
+constexpr int LPS = 2;              // layers per stage
+constexpr int KQ = 2;               // lanes sharing one channel's two rows
+constexpr int KPER = C / KQ;        // 64 inputs per lane
+constexpr int NV = KPER / 8;        // 8 h8 vectors per row per lane
+constexpr int MAT_H = 2 * C * C;    // halves per 2C x C matrix
+constexpr int MAT_F = MAT_H / 2;    // ... in float units of the packed blob
+constexpr int LAYER_F = 3 * MAT_F + 2 * C;  // WC | WP | WR (halves) | residual, skip biases (fp32)
+constexpr int CTX_LAYER_F = MAT_F + 2 * C;
+constexpr int EMB_F = 2 * Q * C;    // fp32 tables
+constexpr int W1_F = Q * C / 2, W2_F = Q * Q / 2;
+constexpr int HEAD_F = W1_F + Q + W2_F + Q;
+constexpr int GRAN = 2 * C, GL = GRAN / 64;
+constexpr int W1NV = (C / 2) / 8;   // conv1: 2 threads per row, 64 inputs each = 8 vectors
+// LDS bytes: layer stage LPS * 64 KB of past-tap weights + vectors; head stage 64 KB of conv1
+constexpr int LDS_BYTES = LPS * MAT_H * 2 + 8192;
+}  // namespace h16
+
+__device__ __forceinline__ float dot8(const h8 w, const h8 x, float acc) {
+  acc = __builtin_amdgcn_fdot2(h2{w[0], w[1]}, h2{x[0], x[1]}, acc, false);
+  acc = __builtin_amdgcn_fdot2(h2{w[2], w[3]}, h2{x[2], x[3]}, acc, false);
+  acc = __builtin_amdgcn_fdot2(h2{w[4], w[5]}, h2{x[4], x[5]}, acc, false);
+  return __builtin_amdgcn_fdot2(h2{w[6], w[7]}, h2{x[6], x[7]}, acc, false);
+}
+// two rows (registers) against the same LDS vector of 8*N halves: four independent chains
+// per row, combined in a fixed order
+template <int N>
+__device__ __forceinline__ void dot2_rows(const h8 (&wa)[N], const h8 (&wb)[N], const _Float16 *xp, float &ra,
+                                          float &rb) {
+  // the vector is fetched four h8 at a time (16 registers live, not 32: next to 128 weight
+  // registers the whole vector spills), the second half requested before the first is used
+  constexpr int CH = 4;
+  static_assert(N % CH == 0, "whole chunks");
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  h8 x[2][CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) x[0][i] = ((const h8 *)xp)[i];
+#pragma unroll
+  for (int ch = 0; ch < N / CH; ++ch) {
+    if (ch + 1 < N / CH) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) x[(ch + 1) & 1][i] = ((const h8 *)xp)[CH * (ch + 1) + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      a[i & 3] = dot8(wa[CH * ch + i], x[ch & 1][i], a[i & 3]);
+      b[i & 3] = dot8(wb[CH * ch + i], x[ch & 1][i], b[i & 3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  ra = (a[0] + a[2]) + (a[1] + a[3]);
+  rb = (b[0] + b[2]) + (b[1] + b[3]);
+}
+// one row whose weights are fetched on the fly (LDS or L2): [N][stride] h8 at column idx.
+// Four vectors at a time behind scheduling fences: hoisted together, the 2 x N vectors of a
+// call (and of the next call) would push resident weight registers to scratch.
+template <int N>
+__device__ __forceinline__ float dot_stream_h(const h8 *wsrc, int stride, int idx, const _Float16 *xp) {
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i0 = 0; i0 < N; i0 += 4) {
+    h8 w[4], x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = wsrc[(i0 + i) * stride + idx];
+      x[i] = ((const h8 *)xp)[i0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = dot8(w[i], x[i], a[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return (a[0] + a[2]) + (a[1] + a[3]);
+}
+__device__ __forceinline__ float pair_sum(float v) { return v + dpp_mov<DPP_XOR1>(v); }
+
+__global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *hand, unsigned *err, int NS,
+                                                             int nb) {
+  using namespace h16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (xcd, slot) -> (sequence, stage): same placement as gen_pipe_kernel (speed only; every edge
+  // verifies its own placement below)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int b, s;
+  if (NS <= PIPE_XCD_CUS) {
+    b = xcd + 8 * (slot / NS);
+    s = slot % NS;
+  } else {
+    const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS, SPX = (NS + XS - 1) / XS;
+    b = xcd / XS;
+    s = (xcd % XS) * SPX + slot;
+    if (slot >= SPX || s >= NS) return;
+  }
+  if (b >= nb) return;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // sticky status
+  const int L = a.L;
+  const int s_next = s + 1 == NS ? 0 : s + 1;
+  u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
+  u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
+  int *iflag = (int *)(smem_b + LDS_BYTES - 64);  // [0] ok flag, [3] fast-edge flag
+  bool fast_edge = false;
+  {
+    unsigned *xcc = err + 16;
+    const unsigned mine = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1;  // HW_REG_XCC_ID[3:0]
+    if (tid == 0) {
+      __hip_atomic_store(xcc + b * NS + s, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned other = 0;
+      for (unsigned spins = 0; spins < (1u << 20) && other == 0; ++spins) {
+        other = __hip_atomic_load(xcc + b * NS + s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other == 0) __builtin_amdgcn_s_sleep(8);
+      }
+      iflag[3] = (other == mine) ? 1 : 0;
+    }
+    __syncthreads();
+    fast_edge = iflag[3] != 0;
+    __syncthreads();
+  }
+
+  if (s < NS - 1) {
+    // ================= layer stage: layers l0 .. l0+nl-1 =================
+    const int l0 = s * LPS, nl = min(LPS, L - l0);
+    const bool fg_group = tid < 256;
+    const int t = tid & 255, c = t / KQ, kq = t % KQ;
+    const bool lead = kq == 0;
+    h8 *wp = (h8 *)smem_b;                                   // [LPS][2*NV][256] h8: past-tap f|g weights
+    float *cur = (float *)(smem_b + LPS * MAT_H * 2);        // [C] residual stream (fp32)
+    float *skin = cur + C;                                   // [C] running skip sum as received
+    _Float16 *curh = (_Float16 *)(skin + C);                 // [C] the stream as the products' operand
+    _Float16 *zbh = curh + C;                                // [C] gated activation
+    _Float16 *pasth = zbh + C;                               // [LPS][C] popped queue entries
+    _Float16 *ctxh = pasth + LPS * C;                        // [C] context column
+    float *ring = a.state + (size_t)b * a.state_per_seq;
+
+    h8 wa[LPS][NV], wb[LPS][NV];  // FG: f_c | g_c current-tap rows; RS: res_c | skip_c
+    float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
+    int doff[LPS], dmask[LPS];
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+      bias_r[j] = 0.f; bias_s[j] = 0.f; pf[j] = 0.f; pg[j] = 0.f; xs[j] = 0.f;
+      doff[j] = 0; dmask[j] = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        wa[j][i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        wb[j][i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      if (j < nl) {
+        const float *lw = a.w + EMB_F + (size_t)(l0 + j) * LAYER_F;
+        const h8 *wc8 = (const h8 *)lw, *wp8 = (const h8 *)(lw + MAT_F), *wr8 = (const h8 *)(lw + 2 * MAT_F);
+        if (fg_group) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            wa[j][i] = wc8[i * 256 + t];
+            wb[j][i] = wc8[(NV + i) * 256 + t];
+          }
+#pragma unroll
+          for (int i = 0; i < 2 * NV; ++i) wp[(j * 2 * NV + i) * 256 + t] = wp8[i * 256 + t];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            wa[j][i] = wr8[i * 256 + t];
+            wb[j][i] = wr8[(NV + i) * 256 + t];
+          }
+          bias_r[j] = lw[3 * MAT_F + c];
+          bias_s[j] = lw[3 * MAT_F + C + c];
+        }
+        const int l = l0 + j;
+        dmask[j] = (1 << (l % a.layer_size)) - 1;
+        doff[j] = ring_offset(l, a.layer_size, C);
+      }
+    }
+
+    // Off the critical path: push this step's layer inputs into the dilation queues, pop the
+    // entries step tn needs (RS lead lanes), then the past-tap half of step tn's f/g sums
+    auto precompute = [&](int tn, bool push) {
+      int tq = t;
+      asm volatile("" : "+v"(tq));  // addresses rebuilt per step: the chain needs the registers
+      const int cq = tq / KQ, kk = tq % KQ;
+      if (!fg_group && lead) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) {
+            float *base = ring + doff[j] + cq;
+            if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
+            const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
+            pasth[j * C + cq] = (_Float16)pv;
+          }
+      }
+      if (a.ctx_tm && fg_group && tq < C)
+        ctxh[tq] = (_Float16)a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
+      __syncthreads();
+      if (fg_group) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) {
+            const h8 *wpj = wp + j * 2 * NV * 256;
+            pf[j] = pair_sum(dot_stream_h<NV>(wpj, 256, tq, pasth + j * C + KPER * kk));
+            pg[j] = pair_sum(dot_stream_h<NV>(wpj + NV * 256, 256, tq, pasth + j * C + KPER * kk));
+            if (a.ctx_tm) {
+              // 1x1 context convs (modules.py:58-63, :75-77), weights streamed from L2
+              const float *wc = a.wctx + (size_t)(l0 + j) * CTX_LAYER_F;
+              pf[j] += pair_sum(dot_stream_h<NV>((const h8 *)wc, 256, tq, ctxh + KPER * kk)) + wc[MAT_F + cq];
+              pg[j] += pair_sum(dot_stream_h<NV>((const h8 *)wc + NV * 256, 256, tq, ctxh + KPER * kk)) +
+                       wc[MAT_F + C + cq];
+            }
+          }
+      }
+    };
+    __syncthreads();
+    precompute(a.t_begin, false);
+
+    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      if (wave == 0) {
+        float v[GL];
+        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
+        if (ok) {
+          // granules 0..C-1 residual stream, C..2C-1 running skip sum
+          cur[2 * lane] = v[0];
+          cur[2 * lane + 1] = v[1];
+          *(h2 *)(curh + 2 * lane) = h2{(_Float16)v[0], (_Float16)v[1]};
+          skin[2 * lane] = v[GL - 2];
+          skin[2 * lane + 1] = v[GL - 1];
+        }
+        if (lane == 0) iflag[0] = ok ? 1 : 0;
+      }
+      lds_barrier();
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
+      float skipacc = (!fg_group && lead) ? skin[c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < LPS; ++j)
+        if (j < nl) {
+          float old = 0.f;
+          if (fg_group) {
+            float f, g;
+            dot2_rows<NV>(wa[j], wb[j], curh + KPER * kq, f, g);
+            f = pair_sum(f) + pf[j];
+            g = pair_sum(g) + pg[j];
+            const float z = gate_fast(f, g);
+            if (lead) zbh[c] = (_Float16)z;
+          } else if (lead) {
+            old = cur[c];  // this layer's input: residual add below, queue push later
+          }
+          lds_barrier();
+          if (!fg_group) {
+            float r, k;
+            dot2_rows<NV>(wa[j], wb[j], zbh + KPER * kq, r, k);
+            r = pair_sum(r);
+            k = pair_sum(k);
+            if (lead) {
+              xs[j] = old;
+              const float outv = (r + bias_r[j]) + old;
+              cur[c] = outv;
+              curh[c] = (_Float16)outv;
+              skipacc += k + bias_s[j];
+              if (j == nl - 1) {
+                // the stage's last layer: hand the activation on before anything else
+                put_granule(outbox + c, epoch, outv, fast_edge);
+                put_granule(outbox + C + c, epoch, skipacc, fast_edge);
+              }
+            }
+          }
+          lds_barrier();
+        }
+      MVN_STAMP(b, s, ts - a.t_begin, 1);
+      if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      if (ts + 1 < a.t_end) {
+        precompute(ts + 1, true);
+      } else if (!fg_group && lead) {
+        // last step of the launch: push only (the next launch pops in its prologue)
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) ring[doff[j] + c + (ts & dmask[j]) * C] = xs[j];
+      }
+    }
+    return;
+  }
+
+  // ============================ head stage ============================
+  {
+    h8 *big = (h8 *)smem_b;                                   // conv1 weights [W1NV][512] h8 (64 KB)
+    _Float16 *a0h = (_Float16 *)(smem_b + W1NV * NT * 16);    // [C]   lrelu(skip)
+    _Float16 *a1h = a0h + C;                                  // [Q]   lrelu(conv1)
+    float *lgb = (float *)(a1h + Q);                          // [Q]   logits
+    const float *E0 = a.w, *E1 = E0 + Q * C;
+    const float *hw = a.w + EMB_F + (size_t)L * LAYER_F;
+    const h8 *W1p = (const h8 *)hw, *W2p = (const h8 *)(hw + W1_F + Q);
+    const float *b1 = hw + W1_F, *b2 = hw + W1_F + Q + W2_F;
+    int32_t *samples = a.samples + (size_t)b * a.stride;
+
+    // conv1: thread (o1 = tid>>1, q1 = tid&1), 64 inputs; conv2: thread (og = tid>>3, q2 = tid&7),
+    // 4 outputs x 32 inputs
+    const int o1 = tid >> 1, q1 = tid & 1, og = tid >> 3, q2 = tid & 7;
+    for (int i = tid; i < W1NV * NT; i += NT) big[i] = W1p[i];
+    h8 w2[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w2[r][i] = W2p[(r * 4 + i) * NT + tid];
+    const float b1r = b1[o1];
+    const float b2r = b2[4 * og + (q2 & 3)];
+    __syncthreads();
+
+    int idx_cur = 0, idx_prev = -1;
+    auto send_h0 = [&](unsigned ep) {  // wave 0: granules c = residual, C + c = skip sum 0
+      const int ic = min(max(idx_cur, 0), Q - 1), ip = min(idx_prev, Q - 1);
+#pragma unroll
+      for (int j = 0; j < C / 64; ++j) {
+        const int ch = lane + 64 * j;
+        float v = E1[ic * C + ch];
+        if (ip >= 0) v += E0[ip * C + ch];
+        put_granule(outbox + ch, ep, v, fast_edge);
+        put_granule(outbox + C + ch, ep, 0.f, fast_edge);
+      }
+    };
+    if (wave == 0) {
+      idx_cur = samples[a.t_begin];
+      idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
+      if (a.t_begin < a.t_end) send_h0(1u);
+      MVN_STAMP(b, s, 0, 1);
+    }
+
+    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      const int u = ts + 1;
+      const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
+      const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
+      int next_idx = 0;
+      if (wave == 0) {
+        if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
+        float v[GL];
+        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
+        if (ok)  // only the skip sum (granules C..2C-1) feeds the head
+          *(h2 *)(a0h + 2 * lane) = h2{(_Float16)leaky(v[GL - 2]), (_Float16)leaky(v[GL - 1])};
+        if (lane == 0) iflag[0] = ok ? 1 : 0;
+      }
+      lds_barrier();
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
+      if (do_head) {
+        {
+          float hsum = dot_stream_h<W1NV>(big, NT, tid, a0h + (C / 2) * q1);
+          hsum = pair_sum(hsum);
+          if (q1 == 0) a1h[o1] = (_Float16)leaky(hsum + b1r);
+        }
+        lds_barrier();
+        {
+          h8 x[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[i] = ((const h8 *)(a1h + 32 * q2))[i];
+          float sv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e0 = dot8(w2[r][0], x[0], 0.f), e1 = dot8(w2[r][1], x[1], 0.f);
+            const float e2 = dot8(w2[r][2], x[2], 0.f), e3 = dot8(w2[r][3], x[3], 0.f);
+            float t4 = (e0 + e2) + (e1 + e3);
+            t4 = quad_sum(t4);
+            sv[r] = t4 + other_quad(t4);
+          }
+          const int sel = q2 & 3;
+          if (q2 < 4) lgb[4 * og + sel] = (sel == 0 ? sv[0] : sel == 1 ? sv[1] : sel == 2 ? sv[2] : sv[3]) + b2r;
+        }
+        lds_barrier();
+      }
+      if (wave == 0) {
+        if (do_head) {
+          const f4 lv = ((const f4 *)lgb)[lane];
+          const float lg[4] = {lv.x, lv.y, lv.z, lv.w};
+          if (a.logits_out && u >= a.logits_t0)
+            ((f4 *)(a.logits_out + ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
+          const int pick = choose_class(lg, a.temperature, a.seed, (uint32_t)u, (uint32_t)b, lane, Q);
+          if (u >= a.n_given) next_idx = pick;
+          idx_prev = idx_cur;
+          idx_cur = next_idx;
+          if (ts + 1 < a.t_end) send_h0(epoch + 1);
+          MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
+          if (lane == 0) {
+            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
+            if (u >= a.n_given) samples[u] = pick;
+          }
+        } else {
+          idx_prev = idx_cur;
+          idx_cur = next_idx;
+          if (ts + 1 < a.t_end) send_h0(epoch + 1);
+          MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
+        }
+      }
+      if (iflag[0] == 0) break;  // hand-off timed out
+    }
+  }
+}
+
+// ---- packing: state_dict layouts (fp32) -> per-thread register order, halves ------------
+// each 2C x C matrix: [2*NV][t (256)] vectors of 8 halves; thread t = KQ*c + kq owns rows
+// (c, C+c) x inputs k = KPER*kq + 8*(iv % NV) + e: vectors 0..NV-1 row c, NV..2NV-1 row C+c
+__device__ __forceinline__ void h16_matrix_index(int h, int &row, int &k) {
+  using namespace h16;
+  const int e = h & 7, v = h >> 3, t = v & 255, iv = v >> 8;
+  row = (iv / NV) * C + t / KQ;
+  k = KPER * (t % KQ) + 8 * (iv % NV) + e;
+}
+__global__ void pack_layer_h16_kernel(const float *fw, const float *gw, const float *rw, const float *rb,
+                                      const float *sw, const float *sb, float *__restrict__ dst) {
+  using namespace h16;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // half index for the matrices
+  _Float16 *dh = (_Float16 *)dst;
+  if (i < 3 * MAT_H) {
+    const int region = i / MAT_H;
+    int row, k;
+    h16_matrix_index(i - region * MAT_H, row, k);
+    const float v = region < 2 ? fg_elem(fw, gw, C, row, region == 0 ? C + k : k)  // WC current, WP past tap
+                               : rs_elem(rw, sw, C, row, k);
+    dh[i] = (_Float16)v;
+  } else if (i < 3 * MAT_H + 2 * C) {
+    const int o = i - 3 * MAT_H;
+    dst[3 * MAT_F + o] = o < C ? rb[o] : sb[o - C];
+  }
+}
+__global__ void pack_ctx_h16_kernel(const float *wcf, const float *bcf, const float *wcg, const float *bcg,
+                                    float *__restrict__ dst) {
+  using namespace h16;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  _Float16 *dh = (_Float16 *)dst;
+  if (i < MAT_H) {
+    int row, k;
+    h16_matrix_index(i, row, k);
+    dh[i] = (_Float16)(row < C ? wcf[(size_t)row * C + k] : wcg[(size_t)(row - C) * C + k]);
+  } else if (i < MAT_H + 2 * C) {
+    const int o = i - MAT_H;
+    dst[MAT_F + o] = o < C ? bcf[o] : bcg[o - C];
+  }
+}
+__global__ void pack_head_h16_kernel(const float *w1, const float *b1, const float *w2, const float *b2,
+                                     float *__restrict__ dst) {
+  using namespace h16;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  _Float16 *d1 = (_Float16 *)dst, *d2 = (_Float16 *)(dst + W1_F + Q);
+  if (i < Q * C) {
+    // conv1: [W1NV][tid (512)] vectors; thread (o1 = tid>>1, q1 = tid&1) owns inputs 64 q1 + 8 iv + e
+    const int e = i & 7, v = i >> 3, tid = v & (NT - 1), iv = v >> 9;
+    d1[i] = (_Float16)w1[(size_t)(tid >> 1) * C + (C / 2) * (tid & 1) + 8 * iv + e];
+  } else if (i < Q * C + Q * Q) {
+    // conv2: [4 r][4 iv][tid (512)] vectors; thread (og = tid>>3, q2 = tid&7): output 4 og + r,
+    // inputs 32 q2 + 8 iv + e
+    const int ii = i - Q * C;
+    const int e = ii & 7, v = ii >> 3, tid = v & (NT - 1), rest = v >> 9, r = rest >> 2, iv = rest & 3;
+    d2[ii] = (_Float16)w2[(size_t)(4 * (tid >> 3) + r) * Q + 32 * (tid & 7) + 8 * iv + e];
+  } else if (i < Q * C + Q * Q + Q) {
+    const int o = i - Q * C - Q * Q;
+    dst[W1_F + o] = b1[o];
+    dst[W1_F + Q + W2_F + o] = b2[o];
+  }
+}
+__global__ void pack_embed_h16_kernel(const float *__restrict__ causal_w, float *__restrict__ dst) {
+  using namespace h16;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= EMB_F) return;
+  const int tap = i / (Q * C), r = i - tap * Q * C, qq = r / C, c = r - qq * C;
+  dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
+}
+
+bool pipe_h16_ok(const mvn_dims *d) {
+  return d->residual_channels == 128 && d->skip_channels == 128 && d->input_channels == 256 &&
+         n_layers(d) >= 1;
+}
+int pipe_h16_stages(const mvn_dims *d) { return (n_layers(d) + h16::LPS - 1) / h16::LPS + 1; }
+int pipe_h16_max_batch(const mvn_dims *d) {
+  const int NS = pipe_h16_stages(d);
+  return NS <= PIPE_XCD_CUS ? 8 * (PIPE_XCD_CUS / NS) : 8 / ((NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS);
+}
+size_t pipe_h16_weights_floats(const mvn_dims *d) {
+  return (size_t)h16::EMB_F + (size_t)n_layers(d) * h16::LAYER_F + h16::HEAD_F;
+}
+size_t pipe_h16_ctx_layer_floats() { return h16::CTX_LAYER_F; }
+
+int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool has_ctx, hipStream_t s) {
+  using namespace h16;
+  const int L = n_layers(d);
+  hipLaunchKernelGGL(pack_embed_h16_kernel, dim3((EMB_F + 255) / 256), dim3(256), 0, s, p->causal_w, packed);
+  for (int l = 0; l < L; ++l)
+    hipLaunchKernelGGL(pack_layer_h16_kernel, dim3((3 * MAT_H + 2 * C + 255) / 256), dim3(256), 0, s,
+                       p->filter_w[l], p->gate_w[l], p->residual_w[l], p->residual_b[l], p->skip_w[l],
+                       p->skip_b[l], packed + EMB_F + (size_t)l * LAYER_F);
+  float *head = packed + EMB_F + (size_t)L * LAYER_F;
+  hipLaunchKernelGGL(pack_head_h16_kernel, dim3((Q * C + Q * Q + Q + 255) / 256), dim3(256), 0, s, p->head1_w,
+                     p->head1_b, p->head2_w, p->head2_b, head);
+  if (has_ctx) {
+    float *ctx = packed + pipe_h16_weights_floats(d);
+    for (int l = 0; l < L; ++l)
+      hipLaunchKernelGGL(pack_ctx_h16_kernel, dim3((MAT_H + 2 * C + 255) / 256), dim3(256), 0, s,
+                         p->ctx_filter_w[l], p->ctx_filter_b[l], p->ctx_gate_w[l], p->ctx_gate_b[l],
+                         ctx + (size_t)l * CTX_LAYER_F);
+  }
+  return check_hip(hipGetLastError(), "pipe_h16_pack");
+}
+
+// `hand`: the hand-off area of the generator state, laid out for pipe_stages(d) stages (the
+// fp32 PIPE variant's count, >= this variant's): granules | 16 flag words | placement words.
+// The status word keeps its offset (mvn_gen_status_offset); this variant uses the first
+// batch * NS inboxes and placement words.
+int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
+  using namespace h16;
+  int NS = pipe_h16_stages(d);
+  int dev = 0, cus = 0, per_cu = 0, coop = 0;
+  const void *fn = (const void *)gen_pipe_h16_kernel;
+  int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_pipe_h16)");
+  if (rc) return rc;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||
+      check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev),
+                "hipDeviceGetAttribute(CUs)") ||
+      check_hip(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev),
+                "hipDeviceGetAttribute(cooperative)") ||
+      check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, LDS_BYTES),
+                "hipOccupancyMaxActiveBlocksPerMultiprocessor(gen_pipe_h16)"))
+    return MVN_ERR_LAUNCH;
+  const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS;
+  const int slots = NS <= PIPE_XCD_CUS ? (batch + 7) / 8 * NS : (NS + XS - 1) / XS;
+  if (cus < 8 * PIPE_XCD_CUS || batch > pipe_h16_max_batch(d) || per_cu < 1 || slots * 8 > per_cu * cus) {
+    set_error("PIPE_F16 variant: %d stages per sequence, at most %d sequences co-resident on %d CUs "
+              "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_h16_max_batch(d), cus, batch);
+    return MVN_ERR_UNSUPPORTED;
+  }
+  const size_t gran_floats_layout = (size_t)batch * pipe_stages(d) * GRAN * 2;  // where the flag words sit
+  unsigned *err = (unsigned *)(hand + gran_floats_layout);
+  const size_t tail_floats = pipe_hand_floats(d, batch) - gran_floats_layout - 16;
+  rc = check_hip(hipMemsetAsync(hand, 0, (size_t)batch * NS * GRAN * 2 * sizeof(float), s),
+                 "hipMemsetAsync(granules)");
+  if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(err + 16, 0, tail_floats * sizeof(float), s), "hipMemsetAsync(placement words)");
+  if (rc) return rc;
+  u64 *gran = (u64 *)hand;
+  GenArgs args = a;
+  int nb = batch;
+  static const bool plain = [] {
+    const char *e = getenv("MOVENET_PIPE_PLAIN_LAUNCH");
+    return e && e[0] == '1';
+  }();
+  if (coop && !plain) {
+    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
+    return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)LDS_BYTES, s),
+                     "mvn_generate(pipe_f16, cooperative launch)");
+  }
+  hipLaunchKernelGGL(gen_pipe_h16_kernel, dim3(slots * 8), dim3(NT), LDS_BYTES, s, args, gran, err, NS, nb);
+  return check_hip(hipGetLastError(), "mvn_generate(pipe_f16)");
+}
+
+}  // namespace mvn

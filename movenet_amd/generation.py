@@ -128,7 +128,10 @@ class RingGenerator:
             self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
         self.t = 0          # number of time steps consumed so far
         self.n_given = 1
-        self.prime_with_forward = True
+        # queues primed by one full-sequence forward (MFMA kernels) instead of stepping; the
+        # forward kernels compute in fp32, so the fp16-operand variant steps over the prompt
+        # itself to keep ONE arithmetic from the first sample on
+        self.prime_with_forward = self.variant != N.GEN_PIPE_F16
         self.repack(state_dict)
 
     def repack(self, state_dict: Dict[str, torch.Tensor]) -> None:
@@ -150,7 +153,7 @@ class RingGenerator:
         """The PIPE variant's sticky status word (a 1-element int32 view into the state), or
         None.  Non-zero since the last ``reset()`` = a hand-off timed out; every later launch
         is then a no-op until the state is zeroed again."""
-        if self.variant != N.GEN_PIPE:
+        if self.variant not in N.PIPE_VARIANTS:
             return None
         word = self.lib.mvn_gen_status_offset(self.dims, self.batch)
         return self.state[word:word + 1].view(torch.int32)
@@ -252,15 +255,15 @@ def auto_plan(dims, batch: int, has_context: bool):
     return "single", N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
 
 
-def max_pipe_batch(dims) -> int:
+def max_pipe_batch(dims, variant: int = N.GEN_PIPE) -> int:
     """Largest batch one PIPE launch holds co-resident for these dims (0: no PIPE kernel)."""
     lib = N.lib()
-    if lib.mvn_gen_variant(dims, N.GEN_PIPE, 1) < 0:
+    if lib.mvn_gen_variant(dims, variant, 1) < 0:
         return 0
     lo, hi = 1, 512
     while lo < hi:  # mvn_gen_variant is monotone in the batch
         mid = (lo + hi + 1) // 2
-        if lib.mvn_gen_variant(dims, N.GEN_PIPE, mid) >= 0:
+        if lib.mvn_gen_variant(dims, variant, mid) >= 0:
             lo = mid
         else:
             hi = mid - 1
@@ -278,16 +281,16 @@ class GroupedGenerator:
 
     def __init__(self, layer_size, stack_size, input_channels, residual_channels, skip_channels,
                  state_dict, batch: int, n_total: int, device, group: int, temperature: float = 0.0,
-                 seed: int = 0, context: Optional[torch.Tensor] = None):
+                 seed: int = 0, context: Optional[torch.Tensor] = None, variant: int = N.GEN_PIPE):
         self.batch, self.n_total, self.device = int(batch), int(n_total), torch.device(device)
-        self.variant = N.GEN_PIPE
+        self.variant = variant
         self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
         self.groups, self.bounds = [], []
         for gi, b0 in enumerate(range(0, self.batch, group)):
             b1 = min(self.batch, b0 + group)
             g = RingGenerator(layer_size, stack_size, input_channels, residual_channels, skip_channels,
                               state_dict, batch=b1 - b0, n_total=n_total, device=device,
-                              variant=N.GEN_PIPE, temperature=temperature,
+                              variant=variant, temperature=temperature,
                               seed=(int(seed) + 0x9E3779B97F4A7C15 * gi) & (2 ** 64 - 1),
                               context=None if context is None else context[b0:b1])
             g.samples = self.samples[b0:b1]  # a contiguous row block of the shared tensor

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _native as N
 from .generation import (GroupedGenerator, PipeHandoffTimeout, RingGenerator, _require_gpu, _stream_ptr,
-                         auto_plan)
+                         auto_plan, max_pipe_batch)
 
 # module constants other movenet files import (movenet/wavenet.py:27-31)
 MAX_AUDIO_FRAMES = 160000
@@ -102,6 +102,25 @@ class WaveNet(nn.Module):
         self._dims = N.make_dims(layer_size, stack_size, Q, C, K)
         self._gen_variant = N.GEN_AUTO
         self.last_generate_fallback = None  # variant a timed-out PIPE call was rerun on
+
+    # ---- precision of generate() ----------------------------------------
+    @property
+    def generate_precision(self) -> str:
+        """"fp32" (default: the reference's own precision) or "fp16": fp16 operands with fp32
+        accumulation in every product of the autoregressive path (BASELINE configs[4]; the
+        reference's precedent for reduced precision is torch.autocast, movenet/trainer.py:124).
+        fp16 exists for C = K = 128, Q = 256 (kernel MVN_GEN_PIPE_F16)."""
+        return "fp16" if self._gen_variant == N.GEN_PIPE_F16 else "fp32"
+
+    @generate_precision.setter
+    def generate_precision(self, value: str) -> None:
+        if value == "fp32":
+            self._gen_variant = N.GEN_AUTO
+        elif value == "fp16":
+            N.check(N.lib().mvn_gen_variant(self._dims, N.GEN_PIPE_F16, 1), "generate_precision = 'fp16'")
+            self._gen_variant = N.GEN_PIPE_F16
+        else:
+            raise ValueError(f"generate_precision must be 'fp32' or 'fp16', got {value!r}")
 
     # ---- shape arithmetic (host only) ---------------------------------
     @property
@@ -205,7 +224,7 @@ class WaveNet(nn.Module):
             if group:
                 gen = GroupedGenerator(self.layer_size, self.stack_size, self.input_channels,
                                        self.residual_channels, self.skip_channels, state,
-                                       group=group, **kw)
+                                       group=group, variant=variant, **kw)
             else:
                 gen = RingGenerator(self.layer_size, self.stack_size, self.input_channels,
                                     self.residual_channels, self.skip_channels, state,
@@ -218,10 +237,13 @@ class WaveNet(nn.Module):
         with torch.cuda.device(audio.device):
             if self._gen_variant == N.GEN_AUTO:
                 kind, what = auto_plan(self._dims, idx.shape[0], context is not None)
+                pipe = N.GEN_PIPE
             else:
-                kind, what = "single", self._gen_variant
+                kind, what, pipe = "single", self._gen_variant, self._gen_variant
+                if pipe == N.GEN_PIPE_F16 and idx.shape[0] > max_pipe_batch(self._dims, pipe):
+                    kind, what = "grouped", max_pipe_batch(self._dims, pipe)  # groups take turns
         try:
-            gen = run(what, 0) if kind == "single" else run(N.GEN_PIPE, what)
+            gen = run(what, 0) if kind == "single" else run(pipe, what)
         except PipeHandoffTimeout:
             # the pipelined kernel needs all its stages co-resident and something else held
             # CUs: rerun THIS call (same prompt, same seed) on a kernel without hand-offs

@@ -36,6 +36,7 @@ def lib() -> C.CDLL:
         h.ro_create.restype = C.c_void_p
         h.ro_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
         h.ro_destroy.argtypes = [C.c_void_p]
+        h.ro_set_half_operands.argtypes = [C.c_void_p, C.c_int]
         h.ro_generate.restype = C.c_int
         h.ro_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int]
@@ -43,9 +44,17 @@ def lib() -> C.CDLL:
     return _lib
 
 
-def pack_weights(sd: Dict[str, torch.Tensor], dims) -> np.ndarray:
-    """state_dict -> the blob layout documented in ring_oracle.c (every matrix [in][out])."""
-    g = lambda k: sd[k].detach().cpu().numpy().astype(np.float32)
+def pack_weights(sd: Dict[str, torch.Tensor], dims, operand_dtype=None) -> np.ndarray:
+    """state_dict -> the blob layout documented in ring_oracle.c (every matrix [in][out]).
+    ``operand_dtype=np.float16``: weight MATRICES rounded to fp16 values (biases and the causal
+    conv's gathered columns stay fp32), for the fp16-operand form."""
+    g32 = lambda k: sd[k].detach().cpu().numpy().astype(np.float32)
+
+    def g(k):
+        v = g32(k)
+        if operand_dtype is None or k.endswith("bias") or k.startswith("causal_conv"):
+            return v
+        return v.astype(operand_dtype).astype(np.float32)
     parts = []
     cw = g("causal_conv.conv.weight")              # (C, Q, 2)
     parts += [cw[:, :, 0].T, cw[:, :, 1].T]        # E0[Q][C], E1[Q][C]
@@ -65,14 +74,17 @@ def pack_weights(sd: Dict[str, torch.Tensor], dims) -> np.ndarray:
 
 
 class RingC:
-    def __init__(self, sd, dims, batch: int):
+    def __init__(self, sd, dims, batch: int, operand_dtype=None):
         self.dims, self.batch = dims, batch
-        self.blob = pack_weights(sd, dims)
+        self.blob = pack_weights(sd, dims, operand_dtype)
         self.h = lib().ro_create(dims.layer_size, dims.stack_size, dims.input_channels,
                                  dims.residual_channels, dims.skip_channels, batch,
                                  self.blob.ctypes.data)
         if not self.h:
             raise MemoryError("ro_create failed")
+        if operand_dtype is not None:
+            assert operand_dtype == np.float16, "only fp16 operands are restated in C"
+            lib().ro_set_half_operands(self.h, 1)
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:
@@ -90,7 +102,8 @@ class RingC:
             raise RuntimeError(f"ro_generate returned {rc}")
 
 
-def generate_ring_c(sd, dims, prompt_idx: np.ndarray, n_samples: int, forced_idx=None, threads: int = 1):
+def generate_ring_c(sd, dims, prompt_idx: np.ndarray, n_samples: int, forced_idx=None, threads: int = 1,
+                    operand_dtype=None):
     """Same contract as wavenet_oracle.generate_ring: (choices (B, n) int64, logits (B, n-RF, Q))."""
     rf, B = dims.receptive_fields, prompt_idx.shape[0]
     samples = np.zeros((B, n_samples), np.int32)
@@ -101,6 +114,6 @@ def generate_ring_c(sd, dims, prompt_idx: np.ndarray, n_samples: int, forced_idx
     samples[:, :rf] = prompt_idx[:, :rf]
     choices = np.zeros((B, n_samples), np.int32)
     logits = np.zeros((B, max(n_samples - rf, 0), dims.input_channels), np.float32)
-    RingC(sd, dims, B).run(samples, n_given, 0, n_samples - 1, threads, choices, logits, rf)
+    RingC(sd, dims, B, operand_dtype).run(samples, n_given, 0, n_samples - 1, threads, choices, logits, rf)
     choices[:, :rf] = prompt_idx[:, :rf]
     return choices.astype(np.int64), logits

@@ -28,6 +28,7 @@
  *              R[C][C] br[C] S[C][K] bs[K]
  *   W1[K][Q] b1[Q] W2[Q][Q] b2[Q]
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,7 +42,21 @@ typedef struct {
   long ring_per_seq;
   int t;
   int *prev; /* [batch], -1 = none (zero padding of the causal conv) */
+  int half_operands; /* fp16-operand / fp32-accumulate form (BASELINE configs[4]): the vector
+                        operand of every product is rounded to fp16 (nearest even); the caller
+                        packs weight matrices already rounded (oracle/ring_c.py) */
 } ring_t;
+
+void ro_set_half_operands(void *h, int on) { ((ring_t *)h)->half_operands = on; }
+
+/* x -> fp16 -> fp32 (F16C, round to nearest even): the operand rounding of the fp16 form */
+static inline void round_operand(const ring_t *r, const float *x, float *y, int n) {
+  if (!r->half_operands) {
+    memcpy(y, x, sizeof(float) * n);
+    return;
+  }
+  for (int i = 0; i < n; ++i) y[i] = _cvtsh_ss(_cvtss_sh(x[i], _MM_FROUND_TO_NEAREST_INT));
+}
 
 static long layer_floats(int C, int K) { return 5L * C * C + C + (long)C * K + K; }
 
@@ -84,7 +99,7 @@ static inline void matvec_acc(const float *restrict W, const float *restrict x, 
 /* one sequence, one time step: consume class `idx` at time t, write Q logits for t+1 */
 static void step_one(ring_t *r, int b, int idx, float *logits) {
   const int C = r->C, K = r->K, Q = r->Q;
-  float h[512], past[512], f[512], g[512], z[512], skip[512], a0[512], a1[2048];
+  float h[512], past[512], f[512], g[512], z[512], skip[512], a0[512], a1[2048], ho[512];
   const float *E0 = r->w, *E1 = r->w + (long)Q * C;
   for (int c = 0; c < C; ++c) h[c] = E1[(long)idx * C + c];
   if (r->prev[b] >= 0)
@@ -98,15 +113,17 @@ static void step_one(ring_t *r, int b, int idx, float *logits) {
     const float *F0 = lw, *F1 = F0 + (long)C * C, *G0 = F1 + (long)C * C, *G1 = G0 + (long)C * C;
     const float *R = G1 + (long)C * C, *br = R + (long)C * C, *S = br + C, *bs = S + (long)C * K;
     float *slot = ring + off + (long)(r->t % d) * C;
-    memcpy(past, slot, sizeof(float) * C);
+    round_operand(r, slot, past, C);
     memcpy(slot, h, sizeof(float) * C);
+    round_operand(r, h, ho, C);
     memset(f, 0, sizeof(float) * C);
     memset(g, 0, sizeof(float) * C);
     matvec_acc(F0, past, f, C, C);
-    matvec_acc(F1, h, f, C, C);
+    matvec_acc(F1, ho, f, C, C);
     matvec_acc(G0, past, g, C, C);
-    matvec_acc(G1, h, g, C, C);
+    matvec_acc(G1, ho, g, C, C);
     for (int c = 0; c < C; ++c) z[c] = tanhf(f[c]) * (1.0f / (1.0f + expf(-g[c])));
+    round_operand(r, z, z, C);
     for (int k = 0; k < K; ++k) skip[k] += bs[k];
     matvec_acc(S, z, skip, C, K);
     for (int c = 0; c < C; ++c) h[c] += br[c];
@@ -116,9 +133,11 @@ static void step_one(ring_t *r, int b, int idx, float *logits) {
   }
   const float *W1 = lw, *b1 = W1 + (long)K * Q, *W2 = b1 + Q, *b2 = W2 + (long)Q * Q;
   for (int k = 0; k < K; ++k) a0[k] = skip[k] > 0.f ? skip[k] : LEAKY * skip[k];
+  round_operand(r, a0, a0, K);
   for (int q = 0; q < Q; ++q) a1[q] = b1[q];
   matvec_acc(W1, a0, a1, K, Q);
   for (int q = 0; q < Q; ++q) a1[q] = a1[q] > 0.f ? a1[q] : LEAKY * a1[q];
+  round_operand(r, a1, a1, Q);
   for (int q = 0; q < Q; ++q) logits[q] = b2[q];
   matvec_acc(W2, a1, logits, Q, Q);
   r->prev[b] = idx;

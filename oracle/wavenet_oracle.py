@@ -201,10 +201,21 @@ def generate_windowed(sd: Dict[str, torch.Tensor], dims: Dims, audio: torch.Tens
 # per-step logits at sizes where the windowed algorithm is too slow.
 # ---------------------------------------------------------------------------
 class RingState:
-    def __init__(self, sd: Dict[str, torch.Tensor], dims: Dims, batch: int):
+    """``operand_dtype=np.float16`` restates the fp16-OPERAND / fp32-ACCUMULATE form of
+    BASELINE configs[4] (reference precedent: torch.autocast, movenet/trainer.py:124): every
+    weight matrix and the vector operand of every product is rounded to fp16 (nearest even),
+    products and sums stay fp32, and so do the residual stream, the skip sum, biases, the
+    gate, the embedding rows (a gather: no product) and the queues.  It is the checker of the
+    MVN_GEN_PIPE_F16 kernel; no reference output exists at this precision (parity against the
+    fp32 fixtures is a TOLERANCE statement, tests/test_fp16_gpu.py)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], dims: Dims, batch: int, operand_dtype=None):
         self.dims = dims
         self.B = batch
-        g = lambda k: sd[k].detach().cpu().numpy().astype(np.float32)
+        self.rnd = (lambda a: a) if operand_dtype is None else (
+            lambda a: np.asarray(a, np.float32).astype(operand_dtype).astype(np.float32))
+        g32 = lambda k: sd[k].detach().cpu().numpy().astype(np.float32)
+        g = lambda k: g32(k) if (k.endswith("bias") or k.startswith("causal_conv")) else self.rnd(g32(k))
         self.E0 = g("causal_conv.conv.weight")[:, :, 0]  # multiplies x[t-1]
         self.E1 = g("causal_conv.conv.weight")[:, :, 1]  # multiplies x[t]
         self.layers = []
@@ -243,19 +254,21 @@ class RingState:
             slot = self.t % L["d"]
             past = L["ring"][slot].copy()
             L["ring"][slot] = h
-            f = past @ L["wf0"].T + h @ L["wf1"].T
-            g = past @ L["wg0"].T + h @ L["wg1"].T
+            ho, po = self.rnd(h), self.rnd(past)  # operands (identity for fp32)
+            f = po @ L["wf0"].T + ho @ L["wf1"].T
+            g = po @ L["wg0"].T + ho @ L["wg1"].T
             if ctx_t is not None:
-                f = f + (ctx_t @ L["wcf"].T + L["bcf"])
-                g = g + (ctx_t @ L["wcg"].T + L["bcg"])
+                co = self.rnd(ctx_t)
+                f = f + (co @ L["wcf"].T + L["bcf"])
+                g = g + (co @ L["wcg"].T + L["bcg"])
             z = np.tanh(f) * (1.0 / (1.0 + np.exp(-g)))
-            z = z.astype(np.float32)
+            z = self.rnd(z.astype(np.float32))
             skip += z @ L["ws"].T + L["bs"]
             h = z @ L["wr"].T + L["br"] + h
         a = np.where(skip > 0, skip, LEAKY_SLOPE * skip).astype(np.float32)
-        a = a @ self.w1.T + self.b1
+        a = self.rnd(a) @ self.w1.T + self.b1
         a = np.where(a > 0, a, LEAKY_SLOPE * a).astype(np.float32)
-        out = a @ self.w2.T + self.b2
+        out = self.rnd(a) @ self.w2.T + self.b2
         self.prev = idx.copy()
         self.t += 1
         return out.astype(np.float32)
@@ -263,7 +276,7 @@ class RingState:
 
 def generate_ring(sd: Dict[str, torch.Tensor], dims: Dims, prompt_idx: np.ndarray,
                   n_samples: int, forced_idx: Optional[np.ndarray] = None,
-                  context: Optional[np.ndarray] = None):
+                  context: Optional[np.ndarray] = None, operand_dtype=None):
     """Greedy (temperature<=0) ring-buffer generation.  prompt_idx (B, >=RF).
     Returns (choices (B,n_samples) int64, logits (B, n_samples-RF, Q)); the
     first RF columns of ``choices`` are the prompt.  With ``forced_idx``
@@ -271,7 +284,7 @@ def generate_ring(sd: Dict[str, torch.Tensor], dims: Dims, prompt_idx: np.ndarra
     still reports what the model would have picked at each step."""
     rf = dims.receptive_fields
     B = prompt_idx.shape[0]
-    st = RingState(sd, dims, B)
+    st = RingState(sd, dims, B, operand_dtype)
     choices = np.zeros((B, n_samples), np.int64)
     choices[:, :rf] = prompt_idx[:, :rf]
     logits = np.zeros((B, max(n_samples - rf, 0), dims.input_channels), np.float32)

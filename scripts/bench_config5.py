@@ -1,25 +1,41 @@
-"""BASELINE config 5 (60-layer, C=K=128, 22.05 kHz): 1 s of audio, batch 1, through the
-fp32 generators for this shape: the 61-stage PIPE kernel (batch <= 4) and the GENERIC one."""
-import os, sys, time
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from movenet_amd.generation import RingGenerator
-from movenet_amd.utils.weights import make_state_dict, synthetic_indices
+"""BASELINE configs[4]: 60-layer WaveNet, C = K = 128, 22.05 kHz, autoregressive generate of 1 s
+of audio on 1 x MI355X -- fp32 (the reference's precision, default) and fp16 operands / fp32
+accumulation (as the config is written) side by side.  Usage: python scripts/bench_config5.py"""
+import json
+import os
+import sys
+import time
 
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from movenet_amd import _native as N  # noqa: E402
+from movenet_amd.generation import RingGenerator  # noqa: E402
+from movenet_amd.utils.weights import make_state_dict, synthetic_indices  # noqa: E402
+
+DEV = "cuda:0"
 cfg = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
-dev = "cuda:0"
-sd = {k: v.to(dev) for k, v in make_state_dict(**cfg, seed=0).items()}
-rf, n_new = 6144, int(sys.argv[1]) if len(sys.argv) > 1 else 2205
-from movenet_amd import _native as N
-for B, variant in ((1, N.GEN_PIPE), (4, N.GEN_PIPE), (1, N.GEN_GENERIC), (16, N.GEN_GENERIC)):
-    g = RingGenerator(**cfg, state_dict=sd, batch=B, n_total=rf + n_new + 1, device=dev, variant=variant)
-    g.prime(synthetic_indices(B, rf, 256, 1).to(dev))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    g.advance(n_new)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    g.check_errors()
-    print(f"config 5, variant {g.variant}, batch {B}: {n_new} samples/sequence in {dt:.3f} s = "
-          f"{dt / n_new * 1e6:.1f} us/step, {B * n_new / dt:.0f} samples/s "
-          f"(1 s of 22.05 kHz audio would take {dt / n_new * 22050:.2f} s)")
+sd = {k: v.to(DEV) for k, v in make_state_dict(**cfg, seed=0).items() if not k.startswith("video_")}
+rf, n_new = 6144, 22050
+flop_per_sample = 2 * (60 * (5 * 128 * 128 + 128 * 128) + 128 * 256 + 256 * 256)  # 11,993,088
+out = {}
+for name, variant, batches in (("fp32 (gen_pipe_kernel<128>, 61 stages)", N.GEN_PIPE, (1, 4)),
+                               ("fp16 operands / fp32 accumulate (gen_pipe_h16_kernel, 31 stages)", N.GEN_PIPE_F16, (1, 4, 8)),
+                               ("fp32 generic kernel", N.GEN_GENERIC, (1,))):
+    for B in batches:
+        g = RingGenerator(**cfg, state_dict=sd, batch=B, n_total=rf + 2 * n_new + 1, device=DEV, variant=variant)
+        g.prime_with_forward = True  # queue priming is outside the timed region either way
+        g.prime(synthetic_indices(B, rf, 256, 1234).to(DEV))
+        steps = n_new if variant != N.GEN_GENERIC else 2000
+        g.advance(steps // 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.advance(steps)
+        g.check_errors()
+        dt = time.perf_counter() - t0
+        out[f"{name}, batch {B}"] = dict(us_per_step=round(dt / steps * 1e6, 2),
+                                         seconds_per_1s_audio=round(dt / steps * n_new, 3),
+                                         samples_per_s=round(B * steps / dt),
+                                         tflops=round(B * steps * flop_per_sample / dt / 1e12, 3))
+        del g
+print(json.dumps(out, indent=1))

@@ -1,0 +1,114 @@
+"""GPU: BASELINE configs[4] as written -- fp16 OPERANDS, fp32 ACCUMULATION -- in the
+autoregressive generator (kernel MVN_GEN_PIPE_F16, C = K = 128, Q = 256).
+
+No reference output exists at this precision (the reference's reduced-precision precedent,
+torch.autocast in movenet/trainer.py:124, needs a CUDA device), so parity is a TOLERANCE
+statement against the pinned fp32 path plus agreement with an independent restatement of the
+same fp16 arithmetic (oracle/ring_oracle.c with half operands):
+
+  * |logits_fp16 - logits_fp32| <= FP16_TOL of the fp32 logit range (2^-11 relative rounding of
+    every operand, accumulated over 60 layers; measured ~1e-3, bound 5e-3);
+  * the kernel is as close to the fp32 logits as the restated fp16 arithmetic is (two fp16
+    implementations differ from each other by as much as from fp32: a value that falls next to
+    an fp16 rounding boundary flips with the last fp32 bit of its accumulation order);
+  * greedy class indices equal the fp32 path's wherever the fp32 top-2 margin exceeds twice
+    the tolerance (margin-checked), and on a free run of sharpened weights.
+fp32 stays the default precision (WaveNet.generate_precision)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import one_hot, synthetic_indices
+from movenet_amd import _native as N
+from movenet_amd.utils.weights import make_state_dict
+from oracle import ring_c
+from oracle import wavenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FP16_TOL = 5e-3
+CFG5 = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
+
+
+def _gen(cfg, sd, batch, n_total, variant, **kw):
+    from movenet_amd.generation import RingGenerator
+    sd = {k: v.to(DEV) for k, v in sd.items()}
+    return RingGenerator(**cfg, state_dict=sd, batch=batch, n_total=n_total, device=DEV, variant=variant, **kw)
+
+
+@pytest.mark.parametrize("cfg,B,n_new", [
+    (dict(layer_size=5, stack_size=2, input_channels=256, residual_channels=128, skip_channels=128), 3, 48),
+    (CFG5, 1, 24),
+    (CFG5, 4, 24),
+])
+def test_fp16_generator_logits_within_tolerance(cfg, B, n_new):
+    sd = make_state_dict(**cfg, seed=2, gain=1.5, head_gain=6.0)
+    dims = O.Dims(**cfg)
+    rf = dims.receptive_fields
+    hist = synthetic_indices(B, rf + n_new, 256, 5)
+    # fp32 oracle (C restatement, pinned by G2/G3) and the fp16-operand restatement
+    c32, l32 = ring_c.generate_ring_c(sd, dims, hist.numpy()[:, :rf], rf + n_new, forced_idx=hist.numpy(), threads=4)
+    c16, l16 = ring_c.generate_ring_c(sd, dims, hist.numpy()[:, :rf], rf + n_new, forced_idx=hist.numpy(), threads=4,
+                                      operand_dtype=np.float16)
+    g = _gen(cfg, sd, B, rf + n_new, N.GEN_PIPE_F16)
+    assert g.variant == N.GEN_PIPE_F16 and not g.prime_with_forward
+    choices, logits = g.teacher_forced(hist.to(DEV), logits_t0=rf)
+    g.check_errors()
+    logits, choices = logits.cpu().numpy(), choices[:, rf:].cpu().numpy()
+    scale = np.abs(l32).max()
+    err_kernel = np.abs(logits - l32).max() / scale
+    err_restated = np.abs(l16 - l32).max() / scale
+    err_between = np.abs(logits - l16).max() / scale
+    print(f"L={dims.n_layers} B={B}: |fp16 kernel - fp32| {err_kernel:.2e}, |fp16 restated - fp32| "
+          f"{err_restated:.2e}, |kernel - restated| {err_between:.2e} of the logit range")
+    assert err_kernel < FP16_TOL and err_between < FP16_TOL
+    assert err_kernel < 3 * err_restated + 1e-4
+    assert err_kernel > 1e-6  # it IS the reduced-precision arithmetic, not the fp32 kernel
+    # margin-checked greedy choices: wherever the fp32 decision is clear, fp16 makes it too
+    top2 = np.sort(l32, axis=2)[:, :, -2:]
+    clear = (top2[:, :, 1] - top2[:, :, 0]) > 2 * FP16_TOL * scale
+    assert clear.mean() > 0.5
+    assert np.array_equal(choices[clear], c32[:, rf:][clear])
+
+
+def test_fp16_free_run_and_model_api():
+    """Sharpened config-5 weights: a 40-step greedy free run in fp16 equals the fp32 run, chunked
+    launches carry the queues, and WaveNet.generate honours generate_precision."""
+    from movenet_amd.wavenet import WaveNet
+    sd = make_state_dict(**CFG5, seed=4, gain=1.5, head_gain=6.0)
+    dims = O.Dims(**CFG5)
+    rf, n_new, B = dims.receptive_fields, 40, 2
+    pidx = synthetic_indices(B, rf, 256, 9)
+    want, wl = ring_c.generate_ring_c(sd, dims, pidx.numpy(), rf + n_new, threads=2)
+    top2 = np.sort(wl, axis=2)[:, :, -2:]
+    assert (top2[:, :, 1] - top2[:, :, 0]).min() > 2 * FP16_TOL * np.abs(wl).max(), "fixture margins too small"
+    g = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16)
+    g.prime(pidx.to(DEV))
+    for _ in range(0, n_new, 8):
+        g.advance(8)
+    g.check_errors()
+    assert np.array_equal(g.samples.cpu().numpy(), want)
+    model = WaveNet(**CFG5)
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV)
+    assert model.generate_precision == "fp32"
+    model.generate_precision = "fp16"
+    out = model.generate(one_hot(pidx, 256).to(DEV), n_samples=rf + n_new, temperature=0.0)
+    assert np.array_equal(out.argmax(1).cpu().numpy(), want)
+    # sampling shares the Philox stream and the step-closing code with the fp32 kernels
+    gs = _gen(CFG5, sd, B, rf + 8, N.GEN_PIPE_F16, temperature=1.0, seed=3)
+    gs.prime(pidx.to(DEV))
+    gs.advance(8)
+    gs.check_errors()
+    assert gs.samples[:, rf:].min().item() >= 0 and len(torch.unique(gs.samples[:, rf:])) > 4
+    with pytest.raises(ValueError):
+        WaveNet(10, 3, 256, 64, 64).generate_precision = "fp16"
+
+
+def test_fp16_capacity_one_xcd():
+    """60 layers = 31 stages of two layers: one XCD per sequence, eight sequences per launch
+    (fp32: 61 stages over two XCDs, four sequences)."""
+    from movenet_amd.generation import max_pipe_batch
+    d5 = N.make_dims(10, 6, 256, 128, 128)
+    assert max_pipe_batch(d5, N.GEN_PIPE) == 4 and max_pipe_batch(d5, N.GEN_PIPE_F16) == 8
+    assert N.lib().mvn_gen_variant(d5, N.GEN_AUTO, 1) == N.GEN_PIPE  # fp32 stays the default
