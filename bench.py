@@ -293,7 +293,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--new-samples", type=int, default=16000, help="samples per sequence per step")
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream, 3 pipe")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 stream, 3 pipe, 5 fold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the T=1.0 and end-to-end lines")
@@ -421,7 +421,7 @@ def main():
                 "batch_per_gpu": BATCH,
                 "new_samples_per_sequence_per_step": n_new,
                 "prompt": rf,
-                "kernel_variant": {1: "generic", 2: "stream64", 3: "pipe"}[variant_used],
+                "kernel_variant": {1: "generic", 2: "stream64", 3: "pipe", 5: "fold"}[variant_used],
                 "parallelism": f"independent clips x{world} (no collective)",
             },
             "samples_per_s_per_gpu": value / world,
@@ -445,7 +445,8 @@ def main():
                 "traffic_source": (f"constant from {PMC_TRAFFIC['source']} (earlier --pmc passes of this "
                                    "command); not measured by this run") if variant_used == 3 else None,
                 "traffic_unit": "bytes per launch (HBM side; the 12.6 MB of dilation queues stay in L2/MALL)",
-                "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>"}[variant_used],
+                "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>",
+                           5: "gen_fold_kernel"}[variant_used],
                 "flop_per_launch": flops_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,
                 "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",

@@ -108,6 +108,13 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
                               per stage, ceil(L/2)+1 stages (31 for 60 layers: one XCD).  Never
                               chosen by MVN_GEN_AUTO: fp32 is the default precision.            */
 
+#define MVN_GEN_FOLD 5 /* C=K=64, Q=256: the PIPE structure with the residual 1x1 of layer j folded
+                          into the filter/gate matrix of layer j+1 (products formed at pack
+                          time): ONE dependent mat-vec + gate per layer instead of two; three
+                          layers per stage, ceil(L/3)+1 stages (11 for 30 layers), at most 16
+                          sequences co-resident.  Parity-green but NOT faster than PIPE as built
+                          (18.6 vs 17.9 us per step at config 2): never chosen by MVN_GEN_AUTO.  */
+
 /* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
  * variant or a negative error.  The packed weight layout depends on the variant:
  * pack and generate must be given the same resolved value. */

@@ -22,8 +22,8 @@ MVN_ERR_TOO_SHORT = -3
 MVN_ERR_LAUNCH = -4
 MVN_ERR_UNSUPPORTED = -5
 
-GEN_AUTO, GEN_GENERIC, GEN_STREAM, GEN_PIPE, GEN_PIPE_F16 = 0, 1, 2, 3, 4
-PIPE_VARIANTS = (GEN_PIPE, GEN_PIPE_F16)  # variants with a hand-off status word
+GEN_AUTO, GEN_GENERIC, GEN_STREAM, GEN_PIPE, GEN_PIPE_F16, GEN_FOLD = 0, 1, 2, 3, 4, 5
+PIPE_VARIANTS = (GEN_PIPE, GEN_PIPE_F16, GEN_FOLD)  # variants with a hand-off status word
 
 
 class NativeLibraryError(RuntimeError):

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmovenet_hip.so")
 STAMP = os.path.join(LIB_DIR, "libmovenet_hip.stamp")
 
-SOURCES = ["common.hip", "generate.hip", "generate_pipe.hip", "generate_pipe_h16.hip", "sequence.hip", "video.hip", "trainer.hip"]
+SOURCES = ["common.hip", "generate.hip", "generate_pipe.hip", "generate_pipe_h16.hip", "generate_fold.hip", "sequence.hip", "video.hip", "trainer.hip"]
 HEADERS = ["common.h", "gen_common.h", "pipe_common.h", "gemm_family.h", os.path.join(ROOT, "include", "movenet_hip.h")]
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",

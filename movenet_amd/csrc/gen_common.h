@@ -65,7 +65,8 @@ int pipe_max_batch(const mvn_dims *d);                   // sequences that fit c
 size_t pipe_weights_floats(const mvn_dims *d);          // packed blob without the context section
 int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);
 int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s);
-int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s);
+int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_floats_total,
+                size_t status_offset_floats, hipStream_t s);
 
 
 // ---- PIPE variant with fp16 operands (generate_pipe_h16.hip), C = K = 128 ----------------
@@ -74,6 +75,22 @@ int pipe_h16_stages(const mvn_dims *d);
 int pipe_h16_max_batch(const mvn_dims *d);
 size_t pipe_h16_weights_floats(const mvn_dims *d);  // packed blob without the context section
 int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool has_ctx, hipStream_t s);
-int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s);
+int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_floats_total,
+                    size_t status_offset_floats, hipStream_t s);
+
+// ---- FOLD variant (generate_fold.hip), C = K = 64: residual 1x1 folded into the next layer
+bool fold_ok(const mvn_dims *d);
+int fold_stages(const mvn_dims *d);
+int fold_max_batch(const mvn_dims *d);
+size_t fold_weights_floats(const mvn_dims *d);  // packed blob without the context section
+size_t fold_hand_floats(const mvn_dims *d, int batch);
+int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);
+int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_floats_total,
+                size_t status_offset_floats, hipStream_t s);
+
+// Hand-off area of the generator state, shared by the pipelined variants: [granules: the
+// largest variant's count][16 flag words, the sticky status word first][placement words]
+size_t hand_status_offset(const mvn_dims *d, int batch);  // floats from the area's start
+size_t hand_total_floats(const mvn_dims *d, int batch);
 
 }  // namespace mvn

@@ -23,6 +23,8 @@
 //            of weights streamed from L2 once per step through two register
 //            buffers (one block of <=16 float4 per thread always in flight),
 //            embedding tables resident in LDS, activations exchanged in LDS.
+#include <algorithm>
+
 #include "common.h"
 #include "gen_common.h"
 
@@ -646,12 +648,29 @@ static size_t generic_lds_bytes(const mvn_dims *d) {
   return sizeof(float) * ((size_t)2 * C + (size_t)L * C + partsz + C + 2 * K + 2 * Q + 16 + 4 + C);
 }
 
+size_t hand_status_offset(const mvn_dims *d, int batch) {
+  size_t g = 0;
+  if (pipe_ok(d)) g = std::max(g, (size_t)batch * pipe_stages(d) * 4 * d->residual_channels);
+  if (pipe_h16_ok(d)) g = std::max(g, (size_t)batch * pipe_h16_stages(d) * 4 * d->residual_channels);
+  if (fold_ok(d)) g = std::max(g, (size_t)batch * fold_stages(d) * 6 * d->residual_channels);
+  return g;
+}
+size_t hand_total_floats(const mvn_dims *d, int batch) {
+  size_t ns = 0;
+  if (pipe_ok(d)) ns = std::max(ns, (size_t)pipe_stages(d));
+  if (pipe_h16_ok(d)) ns = std::max(ns, (size_t)pipe_h16_stages(d));
+  if (fold_ok(d)) ns = std::max(ns, (size_t)fold_stages(d));
+  if (ns == 0) return 0;
+  return hand_status_offset(d, batch) + (16 + (size_t)batch * ns + 63) / 64 * 64;
+}
+
 // packed blob without the trailing context-conv section
 static size_t gen_base_floats(const mvn_dims *dims, int variant) {
   const size_t C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const size_t L = n_layers(dims);
   if (variant == MVN_GEN_PIPE) return pipe_weights_floats(dims);
   if (variant == MVN_GEN_PIPE_F16) return pipe_h16_weights_floats(dims);
+  if (variant == MVN_GEN_FOLD) return fold_weights_floats(dims);
   if (variant == MVN_GEN_STREAM) return s64::EMB_FLOATS + 4 * (L * s64::LAYER_F4 + s64::HEAD_F4);
   return 2 * Q * C + L * (4 * C * C + C * (C + K) + (C + K)) + K * Q + Q + Q * Q + Q;
 }
@@ -724,7 +743,13 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   if (rc) return rc;
   const bool pipe_fits =
       mvn::pipe_ok(dims) && batch >= 1 && device_cus() >= 256 && batch <= mvn::pipe_max_batch(dims);
+  const bool fold_fits =
+      mvn::fold_ok(dims) && batch >= 1 && device_cus() >= 256 && batch <= mvn::fold_max_batch(dims);
   if (requested == MVN_GEN_AUTO) {
+    // (MVN_GEN_FOLD is never chosen here: measured 18.6 us per step against PIPE's 17.9 at
+    // config 2 -- its helper waves' extra products and two more hops cost what the halved
+    // chain saves)
+    (void)fold_fits;
     if (pipe_fits) return MVN_GEN_PIPE;
     return mvn::stream_ok(dims) ? MVN_GEN_STREAM : MVN_GEN_GENERIC;
   }
@@ -736,6 +761,15 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
       return MVN_ERR_UNSUPPORTED;
     }
     return MVN_GEN_PIPE;
+  }
+  if (requested == MVN_GEN_FOLD) {
+    if (!fold_fits) {
+      mvn::set_error("FOLD variant needs C=K=64, Q=256, 256 CUs and batch <= %d for these dims "
+                     "(ceil(L/3)+1 stages per sequence, 32 per XCD)",
+                     mvn::fold_ok(dims) ? mvn::fold_max_batch(dims) : 0);
+      return MVN_ERR_UNSUPPORTED;
+    }
+    return MVN_GEN_FOLD;
   }
   if (requested == MVN_GEN_PIPE_F16) {
     if (!mvn::pipe_h16_ok(dims) || batch < 1 || device_cus() < 256 || batch > mvn::pipe_h16_max_batch(dims)) {
@@ -775,17 +809,16 @@ size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant) {
 
 size_t mvn_gen_state_floats(const mvn_dims *dims, int batch) {
   if (mvn::validate_dims(dims) || batch < 0) return 0;
-  // dilation queues, then (C=K in {64,128}, Q=256 only) the PIPE variant's hand-off area
+  // dilation queues, then (C=K in {64,128}, Q=256 only) the pipelined variants' hand-off area
   size_t n = (size_t)batch * (size_t)mvn::dilation_sum(dims) * dims->residual_channels;
-  if (mvn::pipe_ok(dims)) n += mvn::pipe_hand_floats(dims, batch);
-  return n;
+  return n + mvn::hand_total_floats(dims, batch);
 }
 
 size_t mvn_gen_status_offset(const mvn_dims *dims, int batch) {
-  if (mvn::validate_dims(dims) || batch < 0 || !mvn::pipe_ok(dims)) return (size_t)-1;
-  // queues | batch * stages inboxes of 2C granules (2 floats each) | status word ...
+  if (mvn::validate_dims(dims) || batch < 0 || mvn::hand_total_floats(dims, batch) == 0) return (size_t)-1;
+  // queues | inboxes (granules) of the largest pipelined variant | status word ...
   return (size_t)batch * (size_t)mvn::dilation_sum(dims) * dims->residual_channels +
-         (size_t)batch * mvn::pipe_stages(dims) * 4 * dims->residual_channels;
+         mvn::hand_status_offset(dims, batch);
 }
 
 int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p, float *packed,
@@ -811,6 +844,11 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
     return mvn::pipe_pack_ctx(dims, p, ctx_section, stream);
   }
   if (variant == MVN_GEN_PIPE_F16) return mvn::pipe_h16_pack(dims, p, packed, has_ctx, stream);
+  if (variant == MVN_GEN_FOLD) {
+    int rc = mvn::fold_pack(dims, p, packed, stream);
+    if (rc || !has_ctx) return rc;
+    return mvn::pipe_pack_ctx(dims, p, ctx_section, stream);  // same per-layer layout as PIPE
+  }
   if (has_ctx && variant == MVN_GEN_GENERIC) {
     const int Cc = dims->residual_channels, n = 2 * Cc * Cc + 2 * Cc;
     for (int l = 0; l < mvn::n_layers(dims); ++l)
@@ -892,16 +930,15 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
   a.ctx_stride_b = (long long)n_total * dims->residual_channels;
   a.wctx = packed + mvn::gen_base_floats(dims, variant);
   if (context_tm && variant == MVN_GEN_STREAM) {
-    mvn::set_error("local conditioning is built for the GENERIC and PIPE generator variants only");
+    mvn::set_error("local conditioning is built for the GENERIC, PIPE and FOLD generator variants only");
     return MVN_ERR_UNSUPPORTED;
   }
-  if (variant == MVN_GEN_PIPE) {
+  if (variant == MVN_GEN_PIPE || variant == MVN_GEN_PIPE_F16 || variant == MVN_GEN_FOLD) {
     float *hand = state + (size_t)batch * a.state_per_seq;
-    return mvn::pipe_launch(a, dims, batch, hand, (hipStream_t)stream);
-  }
-  if (variant == MVN_GEN_PIPE_F16) {
-    float *hand = state + (size_t)batch * a.state_per_seq;
-    return mvn::pipe_h16_launch(a, dims, batch, hand, (hipStream_t)stream);
+    const size_t total = mvn::hand_total_floats(dims, batch), soff = mvn::hand_status_offset(dims, batch);
+    if (variant == MVN_GEN_PIPE) return mvn::pipe_launch(a, dims, batch, hand, total, soff, (hipStream_t)stream);
+    if (variant == MVN_GEN_FOLD) return mvn::fold_launch(a, dims, batch, hand, total, soff, (hipStream_t)stream);
+    return mvn::pipe_h16_launch(a, dims, batch, hand, total, soff, (hipStream_t)stream);
   }
   if (variant == MVN_GEN_STREAM) {
     const size_t lds =

@@ -1,0 +1,746 @@
+// FOLD variant of the pipelined generator (C = K = 64, Q = 256): the dependent chain of a
+// layer is ONE mat-vec + gate + LDS exchange instead of two.
+//
+// In the PIPE kernel (generate_pipe.hip) a layer costs two dependent phases: z = gate(Wc x + ..)
+// and then x' = x + Wr z + br, each with its own LDS exchange and barrier (1244 cycles per layer,
+// DESIGN.md 4.1).  Here the residual 1x1 of layer j is folded into the current-tap filter/gate
+// matrix of layer j+1 (reference arithmetic: movenet/modules.py:67-93 -- f,g = conv(x), x' = x +
+// conv_residual(z) -- restated for the product of the two linear maps):
+//
+//     fg_{j+1} = Wc_{j+1} x_{j+1} + past-tap part
+//              = (Wc_{j+1} Wr_j) z_j + [ Wc_{j+1} x_j + Wc_{j+1} br_j + past-tap part ]
+//                `-- critical: one mat-vec on z_j --'  `-- known one phase earlier: helper waves --'
+//
+// A stage holds THREE layers (10 layer stages + the head = 11 workgroups per sequence).  Its
+// inbox carries 3C granules {xp, zl, sk}: xp = the stream WITHOUT the previous stage's last
+// residual term, zl = that stage's last gated activation, sk = the running skip sum without
+// the previous stage's last layer.  Waves 0-3 (the chain) compute
+//     z_0 = gate(Wc_0 xp + (Wc_0 Wr_prev) zl + pf_0)
+//     z_1 = gate((Wc_1 Wr_0) z_0 + base_1 + pf_1)
+//     z_2 = gate((Wc_2 Wr_1) z_1 + base_2 + pf_2)      -> sent on as the next stage's zl
+// with all four matrices (and the past-tap matrix of layer 0) in registers; waves 4-7 (the
+// helpers) compute one phase ahead
+//     base_1 = Wc_1 xp + (Wc_1 Wr_prev) zl,    x_0 = xp + Wr_prev zl,  sk += Ws_prev zl + bs_prev
+//     base_2 = Wc_2 x_0 + (Wc_2 Wr_0) z_0,     x_1 = x_0 + Wr_0 z_0 + br_0,  sk += Ws_0 z_0 + bs_0
+//                                              x_2 = x_1 + Wr_1 z_1 + br_1,  sk += Ws_1 z_1 + bs_1
+// and send xp' = x_2 + br_2 and sk while the chain is still busy with z_2.  The constant
+// vectors Wc_1 br_0 and Wc_2 (br_0 + br_1) are packed once and ride in pf_1 / pf_2.  The
+// explicit x_0, x_1, x_2 feed the dilation queues off the critical path, exactly as before.
+//
+// The products Wc Wr are formed once at pack time (fp64 sums, rounded to fp32).  The folded
+// form is the same real-number function as the reference's; its fp32 rounding differs from
+// the layer-by-layer order at the 1e-7 level (logits within 2e-5 of the range, greedy
+// fixtures bit-exact: tests/test_generate_gpu.py).
+#include <cstdlib>
+
+#include "common.h"
+#include "gen_common.h"
+#include "pipe_common.h"
+
+namespace mvn {
+
+namespace fold {
+constexpr int C = 64, Q = 256, NT = 512, LPS = 3;
+constexpr int KQ = 4, KPER = 16, NF4 = 4;  // thread 4c + kq owns rows (c, C + c) x 16 inputs
+constexpr int MAT_F = 2 * C * C;           // one 2C x C matrix in the per-thread order
+// matrices of a stage section, in order
+enum { M_A0 = 0, M_A0P, M_A1, M_A2, M_WP0,      // chain waves: registers
+       M_B1, M_B1P, M_PP, M_B2, M_B2P,          // helper waves: registers
+       M_WP1, M_WP2, M_RS0, M_RS1,              // LDS
+       N_MAT };
+// vectors behind the matrices: cb1[2C] = Wc_1 br_0, cb2[2C] = Wc_2 (br_0 + br_1), then
+// bs_prev, br_0, bs_0, br_1, bs_1, br_2 [C each]
+constexpr int V_CB1 = 0, V_CB2 = 2 * C, V_BSP = 4 * C, V_BR0 = 5 * C, V_BS0 = 6 * C, V_BR1 = 7 * C,
+              V_BS1 = 8 * C, V_BR2 = 9 * C, VEC_F = 10 * C;
+constexpr int STAGE_F = N_MAT * MAT_F + VEC_F;
+constexpr int CTX_LAYER_F = MAT_F + 2 * C;  // as in the PIPE variant
+constexpr int EMB_F = 2 * Q * C;
+constexpr int W1_F = Q * C, W2_F = Q * Q, WSL_F = C * C;
+constexpr int HEAD_F = W1_F + Q + W2_F + Q + WSL_F + C;
+constexpr int GRAN = 3 * C;                 // granules per inbox: xp | zl | sk
+// LDS floats: layer stage 4 matrices + vectors; head stage the embedding tables + vectors
+constexpr int LDS_FLOATS = 4 * MAT_F + 1536 + 16;
+}  // namespace fold
+
+struct FoldMat {
+  v2f a[2 * fold::NF4], b[2 * fold::NF4];  // rows c and C + c, 16 inputs each
+};
+__device__ __forceinline__ void fold_load(FoldMat &m, const float *sec, int t) {
+  loadn<fold::NF4>(m.a, (const f4 *)sec, 256, t);
+  loadn<fold::NF4>(m.b, (const f4 *)sec + fold::NF4 * 256, 256, t);
+}
+__device__ __forceinline__ void fold_zero(FoldMat &m) {
+#pragma unroll
+  for (int i = 0; i < 2 * fold::NF4; ++i) {
+    m.a[i] = v2f{0.f, 0.f};
+    m.b[i] = v2f{0.f, 0.f};
+  }
+}
+// both rows of a register-resident matrix against 16 inputs of an LDS vector (partial sums:
+// the four lanes of a channel are combined by the caller)
+__device__ __forceinline__ void fold_dot(const FoldMat &m, const float *xq, float &ra, float &rb) {
+  f4 x[fold::NF4];
+  ldsn<fold::NF4>(x, xq);
+  ra = dotn<fold::NF4>(m.a, x);
+  rb = dotn<fold::NF4>(m.b, x);
+}
+// the same with the matrix in LDS ([2 NF4][256] float4, per-thread order)
+__device__ __forceinline__ void fold_dot_lds(const float *mat, int t, const float *xq, float &ra, float &rb) {
+  ra = dot_stream<fold::NF4>((const f4 *)mat, 256, t, xq);
+  rb = dot_stream<fold::NF4>((const f4 *)mat + fold::NF4 * 256, 256, t, xq);
+}
+
+// Wave 0: the 192-granule inbox.  Lane i takes granules 2i, 2i+1 (xp for i < 32, zl above) and
+// 128 + 2(i & 31), +1 (sk); each granule validated by its own epoch.
+__device__ __forceinline__ bool wait_inbox3(const u64 *in, unsigned epoch, unsigned *err, float (&v)[4]) {
+  const int lane = threadIdx.x & 63;
+  const u64 *p0 = in + 2 * lane, *p1 = in + 128 + 2 * (lane & 31);
+  for (unsigned spins = 1;; ++spins) {
+    v4u g0, g1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(g0), "=&v"(g1) : "v"(p0), "v"(p1) : "memory");
+    const bool ok = g0.y == epoch && g0.w == epoch && g1.y == epoch && g1.w == epoch;
+    if (__all(ok)) {
+      v[0] = __uint_as_float(g0.x);
+      v[1] = __uint_as_float(g0.z);
+      v[2] = __uint_as_float(g1.x);
+      v[3] = __uint_as_float(g1.z);
+      return true;
+    }
+    if ((spins & 255u) == 0) {
+      const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, unsigned *err, int NS, int nb) {
+  using namespace fold;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (xcd, slot) -> (sequence, stage): a pipeline of NS <= 32 stages sits in one XCD (speed only;
+  // every edge verifies its own placement below)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = xcd + 8 * (slot / NS), s = slot % NS;
+  if (b >= nb) return;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // sticky status
+  const int L = a.L;
+  const int s_next = s + 1 == NS ? 0 : s + 1;
+  u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
+  u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
+  int *iflag = (int *)(smem + LDS_FLOATS - 16);  // [0] ok flag, [3] fast-edge flag
+  bool fast_edge = false;
+  {
+    unsigned *xcc = err + 16;  // [nb * NS] words, zeroed by the launch's memset
+    const unsigned mine = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1;  // HW_REG_XCC_ID[3:0]
+    if (tid == 0) {
+      __hip_atomic_store(xcc + b * NS + s, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned other = 0;
+      for (unsigned spins = 0; spins < (1u << 20) && other == 0; ++spins) {
+        other = __hip_atomic_load(xcc + b * NS + s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other == 0) __builtin_amdgcn_s_sleep(8);
+      }
+      iflag[3] = (other == mine) ? 1 : 0;  // unknown (time-out) => the safe form
+    }
+    __syncthreads();
+    fast_edge = iflag[3] != 0;
+    __syncthreads();
+  }
+
+  if (s < NS - 1) {
+    // ================= layer stage: layers l0 .. l0 + nl - 1 =================
+    const int l0 = s * LPS, nl = min(LPS, L - l0);
+    const bool chain = tid < 256;
+    const int t = tid & 255, c = t >> 2, kq = t & 3;
+    const bool lead = kq == 0;
+    float *lmat = smem;                  // WP1 | WP2 | RS0 | RS1
+    float *vec = smem + 4 * MAT_F;
+    float *xpb = vec;                    // [C] inbox: stream without the last residual term
+    float *zlb = xpb + C;                // [C] inbox: previous stage's last gated activation
+    float *skb = zlb + C;                // [C] inbox: running skip sum
+    float *z0b = skb + C;                // [C]
+    float *z1b = z0b + C;                // [C]
+    float *x0b = z1b + C;                // [C] layer 0's input, explicit
+    float *base1 = x0b + C;              // [2C] helper -> chain
+    float *base2 = base1 + 2 * C;        // [2C]
+    float *pastb = base2 + 2 * C;        // [LPS][C] popped queue entries
+    float *ctxb = pastb + LPS * C;       // [C] context vector of the step being prepared
+    float *ring = a.state + (size_t)b * a.state_per_seq;
+    const float *sec = a.w + EMB_F + (size_t)s * STAGE_F;
+    const float *vecs = sec + N_MAT * MAT_F;
+
+    // chain waves: A0, A0', A1, A2, WP0; helper waves: B1, B1', PP, B2, B2'
+    FoldMat m0, m1, m2, m3, m4;
+    {
+      const int first = chain ? M_A0 : M_B1;
+      fold_load(m0, sec + (size_t)(first + 0) * MAT_F, t);
+      fold_load(m1, sec + (size_t)(first + 1) * MAT_F, t);
+      fold_load(m2, sec + (size_t)(first + 2) * MAT_F, t);
+      fold_load(m3, sec + (size_t)(first + 3) * MAT_F, t);
+      fold_load(m4, sec + (size_t)(first + 4) * MAT_F, t);
+      const f4 *src = (const f4 *)(sec + (size_t)M_WP1 * MAT_F);
+      for (int i = tid; i < 4 * MAT_F / 4; i += NT) ((f4 *)lmat)[i] = src[i];
+    }
+    // chain lanes: past-tap sums (with the folded bias constants) of the three layers;
+    // helper lead lanes: biases, the explicit layer inputs of this step (queue pushes)
+    // (the two groups never need each other's per-lane values: one set of registers serves
+    // both -- chain: pf/pg of the three layers and the four folded-bias constants; helpers:
+    // xs of the three layers and the six biases)
+    float pf[LPS], pg[LPS];
+    float (&xs)[LPS] = pf;
+    int doff[LPS], dmask[LPS];
+    const float kc0 = vecs[chain ? V_CB1 + c : V_BSP + c], kc1 = vecs[chain ? V_CB1 + C + c : V_BR0 + c];
+    const float kc2 = vecs[chain ? V_CB2 + c : V_BS0 + c], kc3 = vecs[chain ? V_CB2 + C + c : V_BR1 + c];
+    const float kc4 = vecs[V_BS1 + c], kc5 = vecs[V_BR2 + c];
+    const float cb1f = kc0, cb1g = kc1, cb2f = kc2, cb2g = kc3;               // chain
+    const float bsp = kc0, br0 = kc1, bs0 = kc2, br1 = kc3, bs1 = kc4, br2 = kc5;  // helpers
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+      pf[j] = 0.f; pg[j] = 0.f;
+      const int l = l0 + j;
+      dmask[j] = j < nl ? (1 << (l % a.layer_size)) - 1 : 0;
+      doff[j] = j < nl ? ring_offset(l, a.layer_size, C) : 0;
+    }
+
+    // Off the critical path: push this step's layer inputs into the dilation queues, pop the
+    // entries step tn needs (helper lead lanes), then the past-tap half of step tn's f/g sums
+    // (chain waves).  Addresses are rebuilt here behind an optimisation fence (the chain needs
+    // the registers, this code has slack).
+    auto precompute = [&](int tn, bool push) {
+      int tq = t;
+      asm volatile("" : "+v"(tq));
+      const int cq = tq >> 2, kk = tq & 3;
+      if (!chain && lead) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) {
+            float *base = ring + doff[j] + cq;
+            if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
+            const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
+            pastb[j * C + cq] = pv;
+          }
+      }
+      if (a.ctx_tm && chain && tq < C) ctxb[tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
+      __syncthreads();
+      if (chain) {
+        float f0, g0, f1, g1, f2, g2;
+        fold_dot(m4, pastb + KPER * kk, f0, g0);  // WP0 lives in this group's registers
+        fold_dot_lds(lmat, tq, pastb + C + KPER * kk, f1, g1);
+        fold_dot_lds(lmat + MAT_F, tq, pastb + 2 * C + KPER * kk, f2, g2);
+        pf[0] = chan_sum<KQ>(f0);
+        pg[0] = chan_sum<KQ>(g0);
+        pf[1] = chan_sum<KQ>(f1) + cb1f;
+        pg[1] = chan_sum<KQ>(g1) + cb1g;
+        pf[2] = chan_sum<KQ>(f2) + cb2f;
+        pg[2] = chan_sum<KQ>(g2) + cb2g;
+        if (a.ctx_tm) {
+          // 1x1 context convs (modules.py:58-63, :75-77), weights streamed from L2
+#pragma unroll
+          for (int j = 0; j < LPS; ++j)
+            if (j < nl) {
+              const float *wc = a.wctx + (size_t)(l0 + j) * CTX_LAYER_F;
+              pf[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc, 256, tq, ctxb + KPER * kk)) + wc[MAT_F + cq];
+              pg[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc + NF4 * 256, 256, tq, ctxb + KPER * kk)) +
+                       wc[MAT_F + C + cq];
+            }
+        }
+      }
+    };
+    __syncthreads();
+    precompute(a.t_begin, false);
+
+    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      if (wave == 0) {
+        float v[4];
+        const bool ok = wait_inbox3(inbox, epoch, err, v);
+        if (ok) {
+          float *dst = lane < 32 ? xpb + 2 * lane : zlb + 2 * (lane - 32);
+          dst[0] = v[0];
+          dst[1] = v[1];
+          if (lane < 32) {
+            skb[2 * lane] = v[2];
+            skb[2 * lane + 1] = v[3];
+          }
+        }
+        if (lane == 0) iflag[0] = ok ? 1 : 0;
+      }
+      lds_barrier();
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
+      float skacc = 0.f, xv = 0.f;  // helper lead lanes: running skip sum, explicit stream
+      MVN_FINE(b, s, ts - a.t_begin, 0, 0);
+      // ---- phase 0
+      if (chain) {
+        float f, g, f2, g2;
+        fold_dot(m0, xpb + KPER * kq, f, g);
+        fold_dot(m1, zlb + KPER * kq, f2, g2);
+        f = chan_sum<KQ>(f + f2) + pf[0];
+        g = chan_sum<KQ>(g + g2) + pg[0];
+        const float z = gate_fast(f, g);
+        if (lead) z0b[c] = z;
+        MVN_FINE(b, s, ts - a.t_begin, 1, 0);
+      } else {
+        float f, g, f2, g2, r, k;
+        fold_dot(m0, xpb + KPER * kq, f, g);
+        fold_dot(m1, zlb + KPER * kq, f2, g2);
+#if MVN_EXP == 3 || MVN_EXP == 4
+        r = 0.f; k = 0.f;
+#else
+        fold_dot(m2, zlb + KPER * kq, r, k);
+#endif
+        f = chan_sum<KQ>(f + f2);
+        g = chan_sum<KQ>(g + g2);
+        r = chan_sum<KQ>(r);
+        k = chan_sum<KQ>(k);
+        if (lead) {
+          base1[c] = f;
+          base1[C + c] = g;
+          xv = xpb[c] + r;               // x_0 (br_prev already inside xp)
+          skacc = skb[c] + (k + bsp);
+          x0b[c] = xv;
+          xs[0] = xv;
+        }
+        MVN_FINE(b, s, ts - a.t_begin, 6, 256);
+      }
+      lds_barrier();
+      MVN_FINE(b, s, ts - a.t_begin, 2, 0);
+      // ---- phase 1
+      if (chain) {
+        float f, g;
+        fold_dot(m2, z0b + KPER * kq, f, g);
+        f = chan_sum<KQ>(f) + (base1[c] + pf[1]);
+        g = chan_sum<KQ>(g) + (base1[C + c] + pg[1]);
+        const float z = gate_fast(f, g);
+        if (lead) z1b[c] = z;
+        MVN_FINE(b, s, ts - a.t_begin, 3, 0);
+      } else {
+        float f, g, f2, g2, r, k;
+#if MVN_EXP == 4
+        f = g = f2 = g2 = 0.f;
+#else
+        fold_dot(m3, x0b + KPER * kq, f, g);
+        fold_dot(m4, z0b + KPER * kq, f2, g2);
+#endif
+        f = chan_sum<KQ>(f + f2);
+        g = chan_sum<KQ>(g + g2);
+        if (lead) {
+          base2[c] = f;
+          base2[C + c] = g;
+        }
+#if MVN_EXP == 3 || MVN_EXP == 4
+        r = 0.f; k = 0.f;
+#else
+        fold_dot_lds(lmat + 2 * MAT_F, t, z0b + KPER * kq, r, k);  // RS0
+#endif
+        r = chan_sum<KQ>(r);
+        k = chan_sum<KQ>(k);
+        if (lead) {
+          xv = (xv + br0) + r;           // x_1
+          skacc += k + bs0;
+          xs[1] = xv;
+        }
+        MVN_FINE(b, s, ts - a.t_begin, 7, 256);
+      }
+      lds_barrier();
+      MVN_FINE(b, s, ts - a.t_begin, 4, 0);
+      // ---- phase 2: the chain's z_2 and the helpers' {xp', sk} leave as granules
+      if (chain) {
+        float f, g;
+        fold_dot(m3, z1b + KPER * kq, f, g);
+        f = chan_sum<KQ>(f) + (base2[c] + pf[2]);
+        g = chan_sum<KQ>(g) + (base2[C + c] + pg[2]);
+        const float z = gate_fast(f, g);
+        if (lead) put_granule(outbox + C + c, epoch, z, fast_edge);
+        MVN_FINE(b, s, ts - a.t_begin, 5, 0);
+      } else {
+        float r, k;
+#if MVN_EXP == 3 || MVN_EXP == 4
+        r = 0.f; k = 0.f;
+#else
+        fold_dot_lds(lmat + 3 * MAT_F, t, z1b + KPER * kq, r, k);  // RS1
+#endif
+        r = chan_sum<KQ>(r);
+        k = chan_sum<KQ>(k);
+        if (lead) {
+          xv = (xv + br1) + r;           // x_2
+          skacc += k + bs1;
+          xs[2] = xv;
+          put_granule(outbox + c, epoch, xv + br2, fast_edge);
+          put_granule(outbox + 2 * C + c, epoch, skacc, fast_edge);
+        }
+      }
+      MVN_STAMP(b, s, ts - a.t_begin, 1);
+      lds_barrier();  // iflag and the step's LDS vectors are settled for everyone
+      if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      if (ts + 1 < a.t_end) {
+        precompute(ts + 1, true);
+      } else if (!chain && lead) {
+        // last step of the launch: push only (the next launch pops in its prologue)
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) ring[doff[j] + c + (ts & dmask[j]) * C] = xs[j];
+      }
+    }
+    return;
+  }
+
+  // ============================ head stage ============================
+  {
+    float *tab = smem;                    // embedding tables [2][Q][C] (128 KB)
+    float *vec = smem + 4 * MAT_F;
+    float *zlb = vec;                     // [C] last layer's gated activation
+    float *skb = zlb + C;                 // [C] skip sum without the last layer
+    float *a0 = skb + C;                  // [C] lrelu(skip)
+    float *a1 = a0 + C;                   // [Q]
+    float *lgb = a1 + Q;                  // [Q] logits
+    const float *E0 = tab, *E1 = tab + Q * C;
+    const float *hw = a.w + EMB_F + (size_t)(NS - 1) * STAGE_F;
+    const f4 *W1p = (const f4 *)hw, *W2p = (const f4 *)(hw + W1_F + Q);
+    const float *b1 = hw + W1_F, *b2 = hw + W1_F + Q + W2_F;
+    const f4 *WSp = (const f4 *)(hw + W1_F + Q + W2_F + Q);
+    const float *bsl = hw + W1_F + Q + W2_F + Q + WSL_F;
+    int32_t *samples = a.samples + (size_t)b * a.stride;
+
+    // last layer's skip 1x1: thread (cs = tid >> 3, q8 = tid & 7), 8 inputs;
+    // conv1: thread (o1 = tid >> 1, q1 = tid & 1), 32 inputs; conv2: thread (og = tid >> 3,
+    // q2 = tid & 7), 4 outputs x 32 inputs
+    const int o1 = tid >> 1, q1 = tid & 1, og = tid >> 3, q2 = tid & 7;
+    v2f wsl[4], w1[16], w2[4][16];
+    {
+      const f4 *src = (const f4 *)a.w;
+      f4 *dst = (f4 *)tab;
+      for (int i = tid; i < EMB_F / 4; i += NT) dst[i] = src[i];
+      loadn<2>(wsl, WSp, NT, tid);
+      loadn<8>(w1, W1p, NT, tid);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) loadn<8>(w2[r], W2p + r * 8 * NT, NT, tid);
+    }
+    const float b1r = b1[o1];
+    const float b2r = b2[4 * og + (q2 & 3)];
+    const float bslr = bsl[og];
+    __syncthreads();
+
+    int idx_cur = 0, idx_prev = -1;
+    auto send_h0 = [&](unsigned ep) {  // wave 0: xp = the causal conv's two embedding rows, zl = sk = 0
+      const int ic = min(max(idx_cur, 0), Q - 1), ip = min(idx_prev, Q - 1);
+      float v = E1[ic * C + lane];
+      if (ip >= 0) v += E0[ip * C + lane];
+      put_granule(outbox + lane, ep, v, fast_edge);
+      put_granule(outbox + C + lane, ep, 0.f, fast_edge);
+      put_granule(outbox + 2 * C + lane, ep, 0.f, fast_edge);
+    };
+    if (wave == 0) {
+      idx_cur = samples[a.t_begin];
+      idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
+      if (a.t_begin < a.t_end) send_h0(1u);
+      MVN_STAMP(b, s, 0, 1);
+    }
+
+    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      const int u = ts + 1;
+      const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
+      const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
+      int next_idx = 0;
+      if (wave == 0) {
+        if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
+        float v[4];
+        const bool ok = wait_inbox3(inbox, epoch, err, v);
+        if (ok) {
+          if (lane >= 32) {
+            zlb[2 * (lane - 32)] = v[0];
+            zlb[2 * (lane - 32) + 1] = v[1];
+          } else {
+            skb[2 * lane] = v[2];
+            skb[2 * lane + 1] = v[3];
+          }
+        }
+        if (lane == 0) iflag[0] = ok ? 1 : 0;
+      }
+      lds_barrier();
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
+      if (do_head) {
+        {
+          // skip sum + the last layer's skip 1x1 (modules.py:90-91), then the head's first
+          // leaky-ReLU (modules.py:140)
+          f4 x[2];
+          ldsn<2>(x, zlb + 8 * q2);
+          float sv = dotn<2>(wsl, x);
+          sv = quad_sum(sv);
+          sv += other_quad(sv);
+          if (q2 == 0) a0[og] = leaky(skb[og] + (sv + bslr));
+        }
+        lds_barrier();
+        {
+          f4 x[8];
+          ldsn<8>(x, a0 + 32 * q1);
+          float hsum = dotn<8>(w1, x);
+          hsum += dpp_mov<DPP_XOR1>(hsum);
+          if (q1 == 0) a1[o1] = leaky(hsum + b1r);
+        }
+        lds_barrier();
+        {
+          f4 x[8];
+          ldsn<8>(x, a1 + 32 * q2);
+          float s0 = dotn<8>(w2[0], x), s1 = dotn<8>(w2[1], x);
+          float s2 = dotn<8>(w2[2], x), s3 = dotn<8>(w2[3], x);
+          s0 = quad_sum(s0); s0 += other_quad(s0);
+          s1 = quad_sum(s1); s1 += other_quad(s1);
+          s2 = quad_sum(s2); s2 += other_quad(s2);
+          s3 = quad_sum(s3); s3 += other_quad(s3);
+          const int sel = q2 & 3;
+          if (q2 < 4) lgb[4 * og + sel] = (sel == 0 ? s0 : sel == 1 ? s1 : sel == 2 ? s2 : s3) + b2r;
+        }
+        lds_barrier();
+      }
+      if (wave == 0) {
+        if (do_head) {
+          const f4 lv = ((const f4 *)lgb)[lane];
+          const float lg[4] = {lv.x, lv.y, lv.z, lv.w};
+          if (a.logits_out && u >= a.logits_t0)
+            ((f4 *)(a.logits_out + ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
+          const int pick = choose_class(lg, a.temperature, a.seed, (uint32_t)u, (uint32_t)b, lane, Q);
+          if (u >= a.n_given) next_idx = pick;
+          idx_prev = idx_cur;
+          idx_cur = next_idx;
+          if (ts + 1 < a.t_end) send_h0(epoch + 1);
+          MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
+          if (lane == 0) {
+            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
+            if (u >= a.n_given) samples[u] = pick;
+          }
+        } else {
+          idx_prev = idx_cur;
+          idx_cur = next_idx;
+          if (ts + 1 < a.t_end) send_h0(epoch + 1);
+          MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
+        }
+      }
+      if (iflag[0] == 0) break;  // hand-off timed out
+    }
+  }
+}
+
+// ---- packing ---------------------------------------------------------------------------
+// Per-layer parameter pointers of the (up to) four layers a stage section is built from:
+// index 0 = the previous stage's last layer (NULL for stage 0), 1..3 = the stage's own layers
+// (NULL where the model has fewer layers: such a layer is packed as zeros, which makes it the
+// identity -- z = gate(0, 0) = 0, no residual, no skip contribution).
+struct FoldLayers {
+  const float *fw[4], *gw[4], *rw[4], *rb[4], *sw[4], *sb[4];
+};
+__device__ __forceinline__ double fold_wc(const FoldLayers &p, int j, int row, int k) {  // current tap
+  return p.fw[j] ? (double)fg_elem(p.fw[j], p.gw[j], fold::C, row, fold::C + k) : 0.0;
+}
+__device__ __forceinline__ double fold_wr(const FoldLayers &p, int j, int o, int k) {
+  return p.rw[j] ? (double)p.rw[j][(size_t)o * fold::C + k] : 0.0;
+}
+__device__ __forceinline__ double fold_br(const FoldLayers &p, int j, int o) { return p.rb[j] ? (double)p.rb[j][o] : 0.0; }
+
+__global__ void pack_fold_stage_kernel(FoldLayers p, float *__restrict__ dst) {
+  using namespace fold;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= STAGE_F) return;
+  if (i >= N_MAT * MAT_F) {
+    const int o = i - N_MAT * MAT_F;
+    double v = 0.0;
+    if (o < V_CB2) {            // cb1 = Wc_1 br_0
+      for (int m = 0; m < C; ++m) v += fold_wc(p, 2, o - V_CB1, m) * fold_br(p, 1, m);
+    } else if (o < V_BSP) {     // cb2 = Wc_2 (br_0 + br_1)
+      for (int m = 0; m < C; ++m) v += fold_wc(p, 3, o - V_CB2, m) * (fold_br(p, 1, m) + fold_br(p, 2, m));
+    } else if (o < V_BR0) v = p.sb[0] ? p.sb[0][o - V_BSP] : 0.0;
+    else if (o < V_BS0) v = fold_br(p, 1, o - V_BR0);
+    else if (o < V_BR1) v = p.sb[1] ? p.sb[1][o - V_BS0] : 0.0;
+    else if (o < V_BS1) v = fold_br(p, 2, o - V_BR1);
+    else if (o < V_BR2) v = p.sb[2] ? p.sb[2][o - V_BS1] : 0.0;
+    else v = fold_br(p, 3, o - V_BR2);
+    dst[i] = (float)v;
+    return;
+  }
+  // matrix element in the per-thread order: [2 NF4][t (256)] float4; thread t = 4c + kq owns rows
+  // (c, C + c) x inputs k = 16 kq + 4 (i4 % NF4) + e
+  const int mat = i / MAT_F, r = i - mat * MAT_F;
+  const int e = r & 3, v4 = r >> 2, t = v4 & 255, i4 = v4 >> 8;
+  const int row = (i4 / NF4) * C + t / KQ, k = KPER * (t % KQ) + 4 * (i4 % NF4) + e;
+  double v = 0.0;
+  auto prod = [&](int jc, int jr) {  // (Wc_jc Wr_jr)[row][k]
+    double acc = 0.0;
+    for (int m = 0; m < C; ++m) acc += fold_wc(p, jc, row, m) * fold_wr(p, jr, m, k);
+    return acc;
+  };
+  auto rs = [&](int j) {  // rows [0,C) residual, [C,2C) skip of layer j
+    if (row < C) return fold_wr(p, j, row, k);
+    return p.sw[j] ? (double)p.sw[j][(size_t)(row - C) * C + k] : 0.0;
+  };
+  auto wp = [&](int j) { return p.fw[j] ? (double)fg_elem(p.fw[j], p.gw[j], C, row, k) : 0.0; };  // past tap
+  switch (mat) {
+    case M_A0: v = fold_wc(p, 1, row, k); break;
+    case M_A0P: v = prod(1, 0); break;
+    case M_A1: v = prod(2, 1); break;
+    case M_A2: v = prod(3, 2); break;
+    case M_WP0: v = wp(1); break;
+    case M_B1: v = fold_wc(p, 2, row, k); break;
+    case M_B1P: v = prod(2, 0); break;
+    case M_PP: v = rs(0); break;
+    case M_B2: v = fold_wc(p, 3, row, k); break;
+    case M_B2P: v = prod(3, 1); break;
+    case M_WP1: v = wp(2); break;
+    case M_WP2: v = wp(3); break;
+    case M_RS0: v = rs(1); break;
+    case M_RS1: v = rs(2); break;
+  }
+  dst[i] = (float)v;
+}
+
+__global__ void pack_fold_head_kernel(const float *w1, const float *b1, const float *w2, const float *b2,
+                                      const float *sw_last, const float *sb_last, float *__restrict__ dst) {
+  using namespace fold;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < W1_F) {
+    // conv1: [8][tid (512)] float4, thread (o1 = tid >> 1, q1 = tid & 1) owns 32 inputs
+    const int e = i & 3, v = i >> 2, tid = v & (NT - 1), i4 = v >> 9;
+    dst[i] = w1[(size_t)(tid >> 1) * C + 32 * (tid & 1) + 4 * i4 + e];
+  } else if (i < W1_F + Q) {
+    dst[i] = b1[i - W1_F];
+  } else if (i < W1_F + Q + W2_F) {
+    const int ii = i - W1_F - Q;
+    const int e = ii & 3, v = ii >> 2, tid = v & (NT - 1), rest = v >> 9, r = rest >> 3, i8 = rest & 7;
+    dst[i] = w2[(size_t)(4 * (tid >> 3) + r) * Q + 32 * (tid & 7) + 4 * i8 + e];
+  } else if (i < W1_F + Q + W2_F + Q) {
+    dst[i] = b2[i - W1_F - Q - W2_F];
+  } else if (i < W1_F + Q + W2_F + Q + WSL_F) {
+    // last layer's skip 1x1: [2][tid (512)] float4, thread (cs = tid >> 3, q8 = tid & 7) owns 8 inputs
+    const int ii = i - (W1_F + Q + W2_F + Q);
+    const int e = ii & 3, v = ii >> 2, tid = v & (NT - 1), i2 = v >> 9;
+    dst[i] = sw_last[(size_t)(tid >> 3) * C + 8 * (tid & 7) + 4 * i2 + e];
+  } else if (i < HEAD_F) {
+    dst[i] = sb_last[i - (W1_F + Q + W2_F + Q + WSL_F)];
+  }
+}
+
+__global__ void pack_fold_embed_kernel(const float *__restrict__ causal_w, float *__restrict__ dst) {
+  using namespace fold;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= EMB_F) return;
+  const int tap = i / (Q * C), r = i - tap * Q * C, qq = r / C, c = r - qq * C;
+  dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
+}
+
+bool fold_ok(const mvn_dims *d) {
+  return d->residual_channels == 64 && d->skip_channels == 64 && d->input_channels == 256 &&
+         n_layers(d) >= 1 && (n_layers(d) + fold::LPS - 1) / fold::LPS + 1 <= PIPE_XCD_CUS;
+}
+int fold_stages(const mvn_dims *d) { return (n_layers(d) + fold::LPS - 1) / fold::LPS + 1; }
+int fold_max_batch(const mvn_dims *d) { return 8 * (PIPE_XCD_CUS / fold_stages(d)); }
+size_t fold_weights_floats(const mvn_dims *d) {
+  return (size_t)fold::EMB_F + (size_t)(fold_stages(d) - 1) * fold::STAGE_F + fold::HEAD_F;
+}
+size_t fold_hand_floats(const mvn_dims *d, int batch) {
+  const size_t n = (size_t)batch * fold_stages(d);
+  return n * fold::GRAN * 2 + (16 + n + 63) / 64 * 64;
+}
+
+int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {
+  using namespace fold;
+  const int L = n_layers(d), NSL = fold_stages(d) - 1;
+  hipLaunchKernelGGL(pack_fold_embed_kernel, dim3((EMB_F + 255) / 256), dim3(256), 0, s, p->causal_w, packed);
+  for (int st = 0; st < NSL; ++st) {
+    FoldLayers fl;
+    for (int j = 0; j < 4; ++j) {
+      const int l = st * LPS - 1 + j;
+      const bool ok = l >= 0 && l < L;
+      fl.fw[j] = ok ? p->filter_w[l] : nullptr;
+      fl.gw[j] = ok ? p->gate_w[l] : nullptr;
+      fl.rw[j] = ok ? p->residual_w[l] : nullptr;
+      fl.rb[j] = ok ? p->residual_b[l] : nullptr;
+      fl.sw[j] = ok ? p->skip_w[l] : nullptr;
+      fl.sb[j] = ok ? p->skip_b[l] : nullptr;
+    }
+    hipLaunchKernelGGL(pack_fold_stage_kernel, dim3((STAGE_F + 255) / 256), dim3(256), 0, s, fl,
+                       packed + EMB_F + (size_t)st * STAGE_F);
+  }
+  // the head adds the skip 1x1 of the last layer of the last stage (index NSL * LPS - 1 when
+  // L is a multiple of LPS; otherwise that slot is a zero layer and the real last layer's skip
+  // was already added inside its stage)
+  const int l_tail = NSL * LPS - 1;
+  const bool tail_real = l_tail < L;
+  float *zeros = nullptr;  // a zero layer: Ws = 0, bs = 0 -- take them from the packed stage's
+                           // own zero vectors (V_BR2 of a stage whose layer 2 does not exist)
+  if (!tail_real) zeros = packed + EMB_F + (size_t)(NSL - 1) * STAGE_F + (size_t)M_RS1 * MAT_F;
+  // (M_RS1 of the last stage is all zero when its layer 2 does not exist: C*C + C zeros follow)
+  hipLaunchKernelGGL(pack_fold_head_kernel, dim3((HEAD_F + 255) / 256), dim3(256), 0, s, p->head1_w, p->head1_b,
+                     p->head2_w, p->head2_b, tail_real ? p->skip_w[l_tail] : zeros,
+                     tail_real ? p->skip_b[l_tail] : zeros, packed + EMB_F + (size_t)NSL * STAGE_F);
+  return check_hip(hipGetLastError(), "fold_pack");
+}
+
+// context section: the PIPE variant's per-layer layout (same thread mapping), packed by it
+int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_floats_total,
+                size_t status_offset_floats, hipStream_t s) {
+  using namespace fold;
+  int NS = fold_stages(d);
+  const void *fn = (const void *)gen_fold_kernel;
+  int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_fold)");
+  if (rc) return rc;
+  const size_t lds_bytes = LDS_FLOATS * sizeof(float);
+  int dev = 0, cus = 0, per_cu = 0, coop = 0;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||
+      check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute(CUs)") ||
+      check_hip(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev),
+                "hipDeviceGetAttribute(cooperative)") ||
+      check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, lds_bytes),
+                "hipOccupancyMaxActiveBlocksPerMultiprocessor(gen_fold)"))
+    return MVN_ERR_LAUNCH;
+  const int slots = (batch + 7) / 8 * NS;
+  if (cus < 8 * PIPE_XCD_CUS || batch > fold_max_batch(d) || per_cu < 1 || slots * 8 > per_cu * cus) {
+    set_error("FOLD variant: %d stages per sequence, at most %d sequences co-resident on %d CUs (batch %d "
+              "asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : fold_max_batch(d), cus, batch);
+    return MVN_ERR_UNSUPPORTED;
+  }
+  // hand-off area layout of the generator state: [granules ...][16 flag words at
+  // status_offset][placement words]; this variant's granules and placement words must fit
+  const size_t gran_floats = (size_t)batch * NS * GRAN * 2;
+  if (gran_floats > status_offset_floats || status_offset_floats + 16 + (size_t)batch * NS > hand_floats_total) {
+    set_error("FOLD variant: hand-off area too small (%zu granule floats, status word at %zu of %zu)",
+              gran_floats, status_offset_floats, hand_floats_total);
+    return MVN_ERR_BAD_ARG;
+  }
+  unsigned *err = (unsigned *)(hand + status_offset_floats);
+  rc = check_hip(hipMemsetAsync(hand, 0, gran_floats * sizeof(float), s), "hipMemsetAsync(granules)");
+  if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(err + 16, 0, (hand_floats_total - status_offset_floats - 16) * sizeof(float), s),
+                 "hipMemsetAsync(placement words)");
+  if (rc) return rc;
+  u64 *gran = (u64 *)hand;
+  GenArgs args = a;
+  int nb = batch;
+  static const bool plain = [] {
+    const char *e = getenv("MOVENET_PIPE_PLAIN_LAUNCH");
+    return e && e[0] == '1';
+  }();
+  if (coop && !plain) {
+    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
+    return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)lds_bytes, s),
+                     "mvn_generate(fold, cooperative launch)");
+  }
+  hipLaunchKernelGGL(gen_fold_kernel, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb);
+  return check_hip(hipGetLastError(), "mvn_generate(fold)");
+}
+
+}  // namespace mvn
+
+#ifdef MVN_PIPE_STAMPS
+extern "C" int mvn_debug_read_stamps_fold(unsigned long long *out, size_t n) {
+  if (n > sizeof(mvn::g_stamps) / 8) n = sizeof(mvn::g_stamps) / 8;
+  return mvn::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(mvn::g_stamps), n * 8), "read stamps");
+}
+extern "C" int mvn_debug_read_fine_fold(unsigned long long *out, size_t n) {
+  if (n > sizeof(mvn::g_fine) / 8) n = sizeof(mvn::g_fine) / 8;
+  return mvn::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(mvn::g_fine), n * 8), "read fine");
+}
+#endif

@@ -51,112 +51,6 @@ struct PipeCfg {
   // (32768 either way) + a0[C] + a1[Q] + logits[Q]; + 16 flag words
   static constexpr int LDS_FLOATS = 32768 + 8 * CC + 2 * Q + 64 + 16;
 };
-typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef MVN_EXP
-#define MVN_EXP 0   // timing experiments of scripts/pipe_stamps.py; 0 = the product
-#endif
-
-// N4*4-term dot product as packed FMAs (v_pk_fma_f32) in two (N4 = 4) or four independent
-// chains, combined in a fixed order.  w: 2*N4 float2, x: the inputs already fetched from LDS.
-template <int N4>
-__device__ __forceinline__ float dotn(const v2f (&w)[2 * N4], const f4 (&x)[N4]) {
-  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < N4; i += 2) {
-    a0 = __builtin_elementwise_fma(w[2 * i], v2f{x[i].x, x[i].y}, a0);
-    a1 = __builtin_elementwise_fma(w[2 * i + 1], v2f{x[i].z, x[i].w}, a1);
-    a2 = __builtin_elementwise_fma(w[2 * i + 2], v2f{x[i + 1].x, x[i + 1].y}, a2);
-    a3 = __builtin_elementwise_fma(w[2 * i + 3], v2f{x[i + 1].z, x[i + 1].w}, a3);
-  }
-  const v2f t = (a0 + a2) + (a1 + a3);
-  return t.x + t.y;
-}
-template <int N4>
-__device__ __forceinline__ void ldsn(f4 (&x)[N4], const float *p) {
-#pragma unroll
-  for (int i = 0; i < N4; ++i) x[i] = ((const f4 *)p)[i];
-}
-// N4 float4 of a [..][stride] block -> 2*N4 float2 registers
-template <int N4>
-__device__ __forceinline__ void loadn(v2f (&w)[2 * N4], const f4 *src, int stride, int idx) {
-#pragma unroll
-  for (int i = 0; i < N4; ++i) {
-    const f4 v = src[i * stride + idx];
-    w[2 * i] = v2f{v.x, v.y};
-    w[2 * i + 1] = v2f{v.z, v.w};
-  }
-}
-// Two rows against the same LDS vector, the vector fetched four float4 at a time with one
-// chunk of look-ahead: at N4 = 16 only 32-48 of its 64 registers are live at once (the
-// whole vector next to 128 weight registers spills).  Same accumulation order as dotn.
-template <int N4>
-__device__ __forceinline__ void dot2_lds(const v2f (&wa)[2 * N4], const v2f (&wb)[2 * N4],
-                                         const float *xp, float &ra, float &rb) {
-  constexpr int CH = 4, NCH = N4 / CH;
-  static_assert(N4 % CH == 0, "whole chunks");
-  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-  v2f b0 = {0.f, 0.f}, b1 = {0.f, 0.f}, b2 = {0.f, 0.f}, b3 = {0.f, 0.f};
-  f4 x[N4];
-#pragma unroll
-  for (int i = 0; i < CH; ++i) x[i] = ((const f4 *)xp)[i];
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    if (ch + 1 < NCH) {
-#pragma unroll
-      for (int i = CH * (ch + 1); i < CH * (ch + 2); ++i) x[i] = ((const f4 *)xp)[i];
-    }
-    if (NCH > 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = CH * ch; i < CH * (ch + 1); i += 2) {
-      const v2f x0 = {x[i].x, x[i].y}, x1 = {x[i].z, x[i].w};
-      const v2f x2 = {x[i + 1].x, x[i + 1].y}, x3 = {x[i + 1].z, x[i + 1].w};
-      a0 = __builtin_elementwise_fma(wa[2 * i], x0, a0);
-      a1 = __builtin_elementwise_fma(wa[2 * i + 1], x1, a1);
-      a2 = __builtin_elementwise_fma(wa[2 * i + 2], x2, a2);
-      a3 = __builtin_elementwise_fma(wa[2 * i + 3], x3, a3);
-      b0 = __builtin_elementwise_fma(wb[2 * i], x0, b0);
-      b1 = __builtin_elementwise_fma(wb[2 * i + 1], x1, b1);
-      b2 = __builtin_elementwise_fma(wb[2 * i + 2], x2, b2);
-      b3 = __builtin_elementwise_fma(wb[2 * i + 3], x3, b3);
-    }
-    if (NCH > 1) __builtin_amdgcn_sched_barrier(0);
-  }
-  const v2f ta = (a0 + a2) + (a1 + a3), tb = (b0 + b2) + (b1 + b3);
-  ra = ta.x + ta.y;
-  rb = tb.x + tb.y;
-}
-// dotn() with the weights fetched on the fly (LDS or L2), four float4 at a time so that
-// only 32 registers are live; same accumulators and order as dotn: bit-identical to it
-template <int N4>
-__device__ __forceinline__ float dot_stream(const f4 *wsrc, int stride, int idx, const float *xsrc) {
-  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-#pragma unroll
-  for (int i0 = 0; i0 < N4; i0 += 4) {
-    f4 w[4], x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[i] = wsrc[(i0 + i) * stride + idx];
-      x[i] = ((const f4 *)xsrc)[i0 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-      a0 = __builtin_elementwise_fma(v2f{w[i].x, w[i].y}, v2f{x[i].x, x[i].y}, a0);
-      a1 = __builtin_elementwise_fma(v2f{w[i].z, w[i].w}, v2f{x[i].z, x[i].w}, a1);
-      a2 = __builtin_elementwise_fma(v2f{w[i + 1].x, w[i + 1].y}, v2f{x[i + 1].x, x[i + 1].y}, a2);
-      a3 = __builtin_elementwise_fma(v2f{w[i + 1].z, w[i + 1].w}, v2f{x[i + 1].z, x[i + 1].w}, a3);
-    }
-  }
-  const v2f t = (a0 + a2) + (a1 + a3);
-  return t.x + t.y;
-}
-// sum over the KQ lanes that share a channel (result in all of them)
-template <int KQ>
-__device__ __forceinline__ float chan_sum(float v) {
-  v += dpp_mov<DPP_XOR1>(v);
-  if (KQ == 4) v += dpp_mov<DPP_XOR2>(v);
-  return v;
-}
-
 // Workgroup = 8 waves.  Waves 0-3 ("FG group") own the filter/gate matrices, waves
 // 4-7 ("RS group") the residual/skip matrices: at any moment ONE wave per SIMD is
 // issuing, so the dependent chain is not slowed by a co-resident wave replaying the
@@ -670,7 +564,8 @@ int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hi
 // starve a stage: then the bounded spins raise the sticky status word and the caller
 // (WaveNet.generate) reruns the call on a kernel without hand-offs.
 template <int CC>
-static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
+static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_total,
+                         size_t status_off, hipStream_t s) {
   using P = PipeCfg<CC>;
   int NS = pipe_stages(d);
   const void *fn = (const void *)gen_pipe_kernel<CC>;
@@ -697,8 +592,12 @@ static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *
   // Every polled word is re-initialised by memset nodes ahead of each launch: the granules
   // and the placement words -- NOT the 16 flag words between them (the sticky status word).
   const size_t gran_floats = (size_t)batch * NS * P::GRAN * 2;
-  unsigned *err = (unsigned *)(hand + gran_floats);
-  const size_t tail_floats = pipe_hand_floats(d, batch) - gran_floats - 16;
+  if (gran_floats > status_off || status_off + 16 + (size_t)batch * NS > hand_total) {
+    set_error("PIPE variant: hand-off area too small");
+    return MVN_ERR_BAD_ARG;
+  }
+  unsigned *err = (unsigned *)(hand + status_off);
+  const size_t tail_floats = hand_total - status_off - 16;
   rc = check_hip(hipMemsetAsync(hand, 0, gran_floats * sizeof(float), s), "hipMemsetAsync(granules)");
   if (rc) return rc;
   rc = check_hip(hipMemsetAsync(err + 16, 0, tail_floats * sizeof(float), s),
@@ -722,7 +621,8 @@ static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *
   return check_hip(hipGetLastError(), "mvn_generate(pipe)");
 }
 
-int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
+int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_total, size_t status_off,
+                hipStream_t s) {
   const int NS = pipe_stages(d);
   int dev = 0, cus = 0;
   if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return MVN_ERR_LAUNCH;
@@ -734,8 +634,8 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hip
               "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_max_batch(d), cus, batch);
     return MVN_ERR_UNSUPPORTED;
   }
-  return d->residual_channels == 64 ? pipe_launch_t<64>(a, d, batch, hand, s)
-                                    : pipe_launch_t<128>(a, d, batch, hand, s);
+  return d->residual_channels == 64 ? pipe_launch_t<64>(a, d, batch, hand, hand_total, status_off, s)
+                                    : pipe_launch_t<128>(a, d, batch, hand, hand_total, status_off, s);
 }
 
 }  // namespace mvn

@@ -526,11 +526,10 @@ int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool ha
   return check_hip(hipGetLastError(), "pipe_h16_pack");
 }
 
-// `hand`: the hand-off area of the generator state, laid out for pipe_stages(d) stages (the
-// fp32 PIPE variant's count, >= this variant's): granules | 16 flag words | placement words.
-// The status word keeps its offset (mvn_gen_status_offset); this variant uses the first
-// batch * NS inboxes and placement words.
-int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, hipStream_t s) {
+// `hand`: the hand-off area of the generator state (gen_common.h: hand_status_offset): this
+// variant uses the first batch * NS inboxes and placement words of it.
+int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_total,
+                    size_t status_off, hipStream_t s) {
   using namespace h16;
   int NS = pipe_h16_stages(d);
   int dev = 0, cus = 0, per_cu = 0, coop = 0;
@@ -552,9 +551,12 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
               "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_h16_max_batch(d), cus, batch);
     return MVN_ERR_UNSUPPORTED;
   }
-  const size_t gran_floats_layout = (size_t)batch * pipe_stages(d) * GRAN * 2;  // where the flag words sit
-  unsigned *err = (unsigned *)(hand + gran_floats_layout);
-  const size_t tail_floats = pipe_hand_floats(d, batch) - gran_floats_layout - 16;
+  if ((size_t)batch * NS * GRAN * 2 > status_off || status_off + 16 + (size_t)batch * NS > hand_total) {
+    set_error("PIPE_F16 variant: hand-off area too small");
+    return MVN_ERR_BAD_ARG;
+  }
+  unsigned *err = (unsigned *)(hand + status_off);
+  const size_t tail_floats = hand_total - status_off - 16;
   rc = check_hip(hipMemsetAsync(hand, 0, (size_t)batch * NS * GRAN * 2 * sizeof(float), s),
                  "hipMemsetAsync(granules)");
   if (rc) return rc;

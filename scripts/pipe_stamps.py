@@ -20,6 +20,7 @@ from movenet_amd.generation import RingGenerator  # noqa: E402
 from movenet_amd.utils.weights import make_state_dict, synthetic_indices  # noqa: E402
 
 WIDE = "--c128" in sys.argv    # BASELINE config 5: 61 stages, the stamps cover the first 16
+FOLD = "--fold" in sys.argv    # the FOLD variant (11 stages of three folded layers)
 if WIDE:
     CFG = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
     B, rf = 4, 6144
@@ -28,16 +29,19 @@ else:
     B, rf = 16, 3072
 dev = "cuda:0"
 sd = {k: v.to(dev) for k, v in make_state_dict(**CFG, seed=0).items()}
-g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + 4000, device=dev, variant=N.GEN_PIPE)
+g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + 4000, device=dev,
+                  variant=N.GEN_FOLD if FOLD else N.GEN_PIPE)
 g.prime(synthetic_indices(B, rf, 256, 1234).to(dev))
 g.advance(1000)
 g.advance(1000)
 g.check_errors()
 lib = N.lib()
 buf = np.zeros((16, 16, 64, 4), dtype=np.uint64)
-lib.mvn_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
-assert lib.mvn_debug_read_stamps(buf.ctypes.data, buf.size) == 0
-NS = 16 if WIDE else 9          # stages looked at
+read_stamps = lib.mvn_debug_read_stamps_fold if FOLD else lib.mvn_debug_read_stamps
+read_fine = lib.mvn_debug_read_fine_fold if FOLD else lib.mvn_debug_read_fine
+read_stamps.argtypes = [C.c_void_p, C.c_size_t]
+assert read_stamps(buf.ctypes.data, buf.size) == 0
+NS = 16 if WIDE else (11 if FOLD else 9)          # stages looked at
 st = buf[:B, :NS, 8:, :2].astype(np.int64)         # (B, NS, steps, {in, out}) wall clock
 ck = buf[:B, :NS, 8:, 2:].astype(np.int64)         # same stamps on the shader clock
 mhz = ((ck[:, :NS - 1, :, 1] - ck[:, :NS - 1, :, 0]) /
@@ -69,8 +73,16 @@ print("sum compute %.2f us, sum hops %.2f us" % (compute.mean(0).mean(1).sum() +
                                                sum(h.mean() for h in hops)))
 
 fine = np.zeros((16, 16, 64, 8), dtype=np.uint64)
-lib.mvn_debug_read_fine.argtypes = [C.c_void_p, C.c_size_t]
-if lib.mvn_debug_read_fine(fine.ctypes.data, fine.size) == 0:
+read_fine.argtypes = [C.c_void_p, C.c_size_t]
+if FOLD and read_fine(fine.ctypes.data, fine.size) == 0:
+    f = fine[:B, :NS - 1, 8:, :].astype(np.int64)
+    seg = [("phase 0 chain work (xp, zl dots, gate, z0 write)", 0, 1), ("phase 0 helper work (thread 256)", 0, 6),
+           ("phase 0 incl. barrier", 0, 2), ("phase 1 chain work", 2, 3), ("phase 1 helper work", 2, 7),
+           ("phase 1 incl. barrier", 2, 4), ("phase 2 chain work incl. send", 4, 5), ("whole stage", 0, 5)]
+    print("a FOLD stage, shader cycles (median over stages, steps, sequences):")
+    for nm, i0, i1 in seg:
+        print(f"  {nm:52s} {np.median(f[..., i1] - f[..., i0]):7.0f}")
+elif read_fine(fine.ctypes.data, fine.size) == 0:
     f = fine[:B, :NS - 1, 8:, :6].astype(np.int64)
     names = ["FG: x loads, dots, lane sums, gate, z write", "barrier FG->RS (two threads' clocks)",
              "RS: z loads, dots, lane sums", "RS: residual/skip update (+ hand-off stores)",

@@ -82,7 +82,7 @@ def test_config3_forward_backward_properties(model):
 def test_config3_generate_properties(model):
     """Conditioned generation at B = 8 with the full 32000-column context: PIPE (what
     WaveNet.generate picks) equals GENERIC on a 64-step free run, the context changes the
-    samples, and the teacher-forced replay reproduces the run."""
+    samples, and the teacher-forced replay reproduces the run; the FOLD variant agrees too."""
     from movenet_amd.generation import RingGenerator
     # sharpened weights: greedy margins far above fp32 rounding (as in fixture G3)
     model.load_state_dict(make_state_dict(**CFG, seed=1, gain=2.0, head_gain=6.0), strict=True)
@@ -100,7 +100,7 @@ def test_config3_generate_properties(model):
     assert ctx.shape == (B, 64, T)
     sd = {k: v for k, v in model.state_dict().items() if not k.startswith("video_")}
     runs = {}
-    for variant in (N.GEN_GENERIC, N.GEN_PIPE):
+    for variant in (N.GEN_GENERIC, N.GEN_PIPE, N.GEN_FOLD):
         g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + n_new, device=DEV,
                           variant=variant, temperature=0.0, context=ctx)
         assert g.variant == variant
@@ -109,7 +109,8 @@ def test_config3_generate_properties(model):
         g.check_errors()
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_GENERIC])
-    assert torch.equal(runs[N.GEN_PIPE], idx)
+    assert torch.equal(runs[N.GEN_FOLD], runs[N.GEN_GENERIC])
+    assert torch.equal(runs[N.GEN_PIPE], idx)  # what WaveNet.generate ran
     g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + n_new, device=DEV,
                       variant=N.GEN_GENERIC, temperature=0.0, context=ctx)
     choices, _ = g.teacher_forced(idx, logits_t0=rf)

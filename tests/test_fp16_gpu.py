@@ -79,15 +79,23 @@ def test_fp16_free_run_and_model_api():
     dims = O.Dims(**CFG5)
     rf, n_new, B = dims.receptive_fields, 40, 2
     pidx = synthetic_indices(B, rf, 256, 9)
-    want, wl = ring_c.generate_ring_c(sd, dims, pidx.numpy(), rf + n_new, threads=2)
-    top2 = np.sort(wl, axis=2)[:, :, -2:]
-    assert (top2[:, :, 1] - top2[:, :, 0]).min() > 2 * FP16_TOL * np.abs(wl).max(), "fixture margins too small"
     g = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16)
     g.prime(pidx.to(DEV))
     for _ in range(0, n_new, 8):
         g.advance(8)
     g.check_errors()
-    assert np.array_equal(g.samples.cpu().numpy(), want)
+    want = g.samples.cpu().numpy()
+    g1 = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16)
+    g1.prime(pidx.to(DEV))
+    g1.advance(n_new)
+    assert np.array_equal(g1.samples.cpu().numpy(), want)  # chunked launches carry the queues
+    # the fp32 path (C restatement) fed the fp16 run's own history: wherever its decision is
+    # clear (top-2 margin above twice the tolerance) the fp16 run made the same one
+    c32, l32 = ring_c.generate_ring_c(sd, dims, pidx.numpy(), rf + n_new, forced_idx=want, threads=2)
+    top2 = np.sort(l32, axis=2)[:, :, -2:]
+    clear = (top2[:, :, 1] - top2[:, :, 0]) > 2 * FP16_TOL * np.abs(l32).max()
+    assert clear.mean() > 0.5 and np.array_equal(want[:, rf:][clear], c32[:, rf:][clear])
+    assert len(np.unique(want[:, rf:])) > 4
     model = WaveNet(**CFG5)
     model.load_state_dict(sd, strict=False)
     model.to(DEV)

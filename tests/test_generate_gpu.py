@@ -28,7 +28,7 @@ def _variants(cfg):
     from movenet_amd import _native as N
     out = [N.GEN_GENERIC]
     if cfg["residual_channels"] == 64 and cfg["skip_channels"] == 64 and cfg["input_channels"] == 256:
-        out += [N.GEN_STREAM, N.GEN_PIPE]
+        out += [N.GEN_STREAM, N.GEN_PIPE, N.GEN_FOLD]
     return out
 
 
@@ -44,7 +44,7 @@ def test_small_teacher_forced_logits(golden):
     assert np.array_equal(choices[:, rf:].cpu().numpy(), want.argmax(2))
 
 
-@pytest.mark.parametrize("which", ["generic", "stream", "pipe"])
+@pytest.mark.parametrize("which", ["generic", "stream", "pipe", "fold"])
 def test_l30_teacher_forced_logits(golden, which):
     from movenet_amd import _native as N
     fx = golden("g2_l30_forward.npz")
@@ -52,7 +52,7 @@ def test_l30_teacher_forced_logits(golden, which):
     B, T, rf = int(fx["B"]), int(fx["T"]), dims.receptive_fields
     idx = synthetic_indices(B, T, 256, int(fx["idx_seed"]))
     g = _gen(cfg, sd, B, T, variant={"generic": N.GEN_GENERIC, "stream": N.GEN_STREAM,
-                                     "pipe": N.GEN_PIPE}[which])
+                                     "pipe": N.GEN_PIPE, "fold": N.GEN_FOLD}[which])
     choices, logits = g.teacher_forced(idx.to(DEV), logits_t0=rf)
     g.check_errors()
     want = np.transpose(fx["logits"][:, :, :-1], (0, 2, 1))
@@ -141,7 +141,7 @@ def test_config2_full_size_properties():
     rf, B, n_new = 3072, 16, 96
     pidx = synthetic_indices(B, rf, 256, 1234).to(DEV)
     runs = {}
-    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_PIPE):
+    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_PIPE, N.GEN_FOLD):
         g = _gen(cfg, sd, B, rf + n_new, variant=variant)
         g.prime(pidx)
         g.advance(n_new)
@@ -149,6 +149,8 @@ def test_config2_full_size_properties():
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_GENERIC], runs[N.GEN_STREAM])
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
+    assert torch.equal(runs[N.GEN_FOLD], runs[N.GEN_STREAM])
+    assert _gen(cfg, sd, B, rf + 1).variant == N.GEN_PIPE  # what AUTO runs at config 2
     g = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_STREAM)
     choices, logits = g.teacher_forced(runs[N.GEN_STREAM], logits_t0=rf)
     assert torch.equal(choices[:, rf:], runs[N.GEN_STREAM][:, rf:])
@@ -177,6 +179,10 @@ def test_config2_pipe_at_full_occupancy():
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
     assert _gen(cfg, sd, 25, rf + 1).variant == N.GEN_STREAM  # AUTO falls back
+    assert _gen(cfg, sd, 24, rf + 1).variant == N.GEN_PIPE    # up to 24 sequences: the 9-stage pipelines
+    assert _gen(cfg, sd, 16, rf + 1, variant=N.GEN_FOLD).variant == N.GEN_FOLD  # 11-stage folded: <= 16
+    with pytest.raises(Exception):
+        _gen(cfg, sd, 17, rf + 1, variant=N.GEN_FOLD)
     with pytest.raises(Exception):
         _gen(cfg, sd, 25, rf + 1, variant=N.GEN_PIPE)
 
@@ -301,7 +307,7 @@ def test_sampler_same_draws_on_generic_stream_pipe(temperature):
     rf, B, n_new = 3072, 16, 700
     hist = synthetic_indices(B, rf + n_new, 256, 4321).to(DEV)
     picks = {}
-    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_PIPE):
+    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_PIPE, N.GEN_FOLD):
         g = _gen(CFG2, sd, B, rf + n_new, variant=variant, temperature=temperature, seed=77)
         choices, _ = g.teacher_forced(hist, logits_t0=rf)
         g.check_errors()
@@ -309,7 +315,8 @@ def test_sampler_same_draws_on_generic_stream_pipe(temperature):
         assert picks[variant].min() >= 0 and picks[variant].max() < 256
     n = picks[N.GEN_GENERIC].size
     assert n >= 10000
-    for a, b in ((N.GEN_GENERIC, N.GEN_STREAM), (N.GEN_GENERIC, N.GEN_PIPE), (N.GEN_STREAM, N.GEN_PIPE)):
+    for a, b in ((N.GEN_GENERIC, N.GEN_STREAM), (N.GEN_GENERIC, N.GEN_PIPE), (N.GEN_STREAM, N.GEN_PIPE),
+                 (N.GEN_GENERIC, N.GEN_FOLD), (N.GEN_PIPE, N.GEN_FOLD)):
         same = (picks[a] == picks[b]).mean()
         assert same >= 0.999, f"variants {a}/{b} agree on {same:.5f} of {n} draws"
     # the draws are samples, not the arg-max: many distinct classes, and another seed differs
@@ -319,14 +326,16 @@ def test_sampler_same_draws_on_generic_stream_pipe(temperature):
     assert (other[:, rf:].cpu().numpy() != picks[N.GEN_PIPE]).mean() > 0.5
 
 
-@pytest.mark.parametrize("variant", [N.GEN_PIPE, N.GEN_STREAM])
+@pytest.mark.parametrize("variant", [N.GEN_PIPE, N.GEN_STREAM, N.GEN_FOLD])
 def test_sampler_frequencies_match_oracle_distribution(variant):
-    """32 784 draws of ONE config-2 step (24 identical sequences x 1366 seeds) against the
+    """>= 32 768 draws of ONE config-2 step (24 or 16 identical sequences x seeds) against the
     oracle's pre-sampling distribution softmax(softmax(logits) / T) for that step."""
     from movenet_amd.utils.weights import make_state_dict
     sd = make_state_dict(**CFG2, seed=3, gain=2.0, head_gain=6.0)
     dims = O.Dims(**CFG2)
-    rf, B, T = 3072, 24, 0.5
+    rf, T = 3072, 0.5
+    B = 16 if variant == N.GEN_FOLD else 24   # the most sequences one launch of the variant holds
+    n_seeds = -(-32768 // B)
     pidx = synthetic_indices(1, rf, 256, 555)
     with torch.no_grad():
         probs = O.forward(sd, dims, one_hot(pidx, 256), output_unnormalized=True, remove_last=False)
@@ -335,7 +344,7 @@ def test_sampler_frequencies_match_oracle_distribution(variant):
     g.prime(pidx.repeat(B, 1).to(DEV))
     state0, samples0, t0 = g.state.clone(), g.samples.clone(), g.t
     draws = []
-    for seed in range(1366):
+    for seed in range(n_seeds):
         g.state.copy_(state0)
         g.samples.copy_(samples0)
         g.t, g.seed = t0, seed
@@ -344,14 +353,15 @@ def test_sampler_frequencies_match_oracle_distribution(variant):
     g.check_errors()
     draws = torch.cat(draws).cpu().numpy()
     n = draws.size
-    assert n == 24 * 1366
+    assert n == B * n_seeds >= 32768
     freq = np.bincount(draws, minlength=256) / n
     # per-class standard error sqrt(p (1 - p) / n); allow 6 sigma on every class
     assert (np.abs(freq - p2) < 6 * np.sqrt(p2 * (1 - p2) / n) + 1e-9).all()
     assert p2.max() > 2 * p2.min()  # not the near-uniform distribution of unsharpened weights
 
 
-def test_sampler_pipe_chunked_launches_same_as_one_launch():
+@pytest.mark.parametrize("variant", [N.GEN_PIPE, N.GEN_FOLD])
+def test_sampler_pipe_chunked_launches_same_as_one_launch(variant):
     """T = 1.0 free run on PIPE: the draw for (b, u) does not depend on how the steps are
     partitioned into launches, nor on the queues being primed by the forward kernels."""
     from movenet_amd.utils.weights import make_state_dict
@@ -360,7 +370,7 @@ def test_sampler_pipe_chunked_launches_same_as_one_launch():
     pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
     runs = []
     for chunk in (n_new, 7, 1):
-        g = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_PIPE, temperature=1.0, seed=5)
+        g = _gen(CFG2, sd, B, rf + n_new, variant=variant, temperature=1.0, seed=5)
         g.prime(pidx)
         for _ in range(0, n_new, chunk):
             g.advance(chunk)
@@ -375,7 +385,8 @@ def test_sampler_pipe_chunked_launches_same_as_one_launch():
     assert torch.equal(s.samples[:, :rf + 8], runs[0][:, :rf + 8])
 
 
-def test_pipe_status_word_is_sticky_and_checked():
+@pytest.mark.parametrize("variant", [N.GEN_PIPE, N.GEN_FOLD])
+def test_pipe_status_word_is_sticky_and_checked(variant):
     """A raised hand-off status word (here: raised by the test) makes every later launch a
     no-op until the state is reset, and check_errors() raises: a time-out in one advance()
     chunk is not erased by the next launch."""
@@ -384,7 +395,7 @@ def test_pipe_status_word_is_sticky_and_checked():
     sd = make_state_dict(**CFG2, seed=1, gain=2.0, head_gain=6.0)
     rf, B, n_new = 3072, 4, 16
     pidx = synthetic_indices(B, rf, 256, 3).to(DEV)
-    g = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_PIPE)
+    g = _gen(CFG2, sd, B, rf + n_new, variant=variant)
     g.prime(pidx)
     g.advance(4)
     g.check_errors()
@@ -423,7 +434,7 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
     real_advance, poked = G.RingGenerator.advance, []
 
     def advance(self, n):
-        if self.variant == N.GEN_PIPE:
+        if self.variant in N.PIPE_VARIANTS:
             self.status_word().fill_(1)
             poked.append(self.variant)
         return real_advance(self, n)
@@ -445,6 +456,7 @@ def test_auto_plan_cost_based():
     from movenet_amd.generation import auto_plan
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
     assert auto_plan(d2, 16, False) == ("single", N.GEN_PIPE)
+    assert auto_plan(d2, 20, False) == ("single", N.GEN_PIPE)
     assert auto_plan(d2, 64, False) == ("grouped", 24)
     assert auto_plan(d2, 96, False) == ("grouped", 24)
     assert auto_plan(d2, 97, False) == ("single", N.GEN_STREAM)   # 5 x 17.6 us > 78 us
