@@ -60,7 +60,14 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_weights_floats(d5, N.GEN_GENERIC) == n5 + 60 * (2 * 128 * 128 + 256)
     assert lib.mvn_gen_state_floats(d5, 1) == 6138 * 128 + 61 * 512 + 128
     assert lib.mvn_gen_status_offset(d5, 1) == 6138 * 128 + 61 * 512
-    assert lib.mvn_gen_status_offset(d2, 16) == 16 * (3069 * 64 + 9 * 256)
+    # C=K=64: the hand-off area is sized for the largest pipelined variant (FOLD: 11 stages of
+    # 192 granules), the status word follows its granules
+    assert lib.mvn_gen_status_offset(d2, 16) == 16 * (3069 * 64 + 11 * 384)
+    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 16) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 17) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 8) == N.GEN_PIPE_F16
+    assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 9) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d2, N.GEN_PIPE_F16, 1) == N.MVN_ERR_UNSUPPORTED
     d1 = N.make_dims(2, 2, 64, 16, 16)
     assert lib.mvn_gen_variant(d1, N.GEN_AUTO, 2) == N.GEN_GENERIC
     assert lib.mvn_gen_variant(d1, N.GEN_STREAM, 2) == N.MVN_ERR_UNSUPPORTED
@@ -73,7 +80,7 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_weights_floats(d2, N.GEN_PIPE) == 856320 + ctx
     # dilation queues: D*C floats per sequence (786 KB fp32) + the PIPE
     # variant's hand-off area (9 stages x 128 eight-byte granules per sequence + flags)
-    assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 9 * 256 + 64
+    assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 11 * 384 + 64
     assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 9 * 256) + 192
     assert lib.mvn_gen_state_floats(d1, 2) == 2 * 6 * 16
     assert lib.mvn_gen_status_offset(d1, 2) == 2 ** 64 - 1
