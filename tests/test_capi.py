@@ -78,10 +78,10 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_weights_floats(d2, N.GEN_GENERIC) == 856320 + ctx
     assert lib.mvn_gen_weights_floats(d2, N.GEN_STREAM) == 856320 + ctx
     assert lib.mvn_gen_weights_floats(d2, N.GEN_PIPE) == 856320 + ctx
-    # dilation queues: D*C floats per sequence (786 KB fp32) + the PIPE
-    # variant's hand-off area (9 stages x 128 eight-byte granules per sequence + flags)
+    # dilation queues: D*C floats per sequence (786 KB fp32) + the pipelined variants'
+    # hand-off area (the largest: FOLD's 11 stages x 192 eight-byte granules per sequence + flags)
     assert lib.mvn_gen_state_floats(d2, 1) == 3069 * 64 + 11 * 384 + 64
-    assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 9 * 256) + 192
+    assert lib.mvn_gen_state_floats(d2, 16) == 16 * (3069 * 64 + 11 * 384) + 192
     assert lib.mvn_gen_state_floats(d1, 2) == 2 * 6 * 16
     assert lib.mvn_gen_status_offset(d1, 2) == 2 ** 64 - 1
 
