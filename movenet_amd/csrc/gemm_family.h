@@ -390,14 +390,6 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
     // loop they would occupy 32-48 registers next to 64 accumulators and 64 staging registers)
     int srow_q = srow;
     asm volatile("" : "+v"(srow_q));
-    const float *ap[8], *xp[4 * NB], *xq[4 * NB];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) ap[p] = op.a_ptr(b, mblk * 128 + 16 * p + srow_q);
-#pragma unroll
-    for (int p = 0; p < 4 * NB; ++p) {
-      xp[p] = op.x_ptr(b, nblk * 64 * NB + 16 * p + srow_q);
-      xq[p] = Op::X_PRODUCT ? op.x_ptr2(b, nblk * 64 * NB + 16 * p + srow_q) : nullptr;
-    }
     // A rows whose range misses the tile altogether (the skip gradient before t_skip0, the
     // absent dxo rows of the last layer) still take the unmasked path: they load a row that
     // IS valid here and are zeroed at the LDS store (azero, bit p)
@@ -405,19 +397,19 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
     unsigned zero_bits = 0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int m = mblk * 128 + 16 * p + srow;
+      const int m = mblk * 128 + 16 * p + srow_q;
       const int lo = op.a_lo(m), hi = op.a_hi(m);
       const bool full = t0 >= lo && t0 + W2_T <= hi, none = t0 + W2_T <= lo || t0 >= hi;
       inter = inter && (full || none);
       if (none) zero_bits |= 1u << p;
     }
     // Op::X_ABSENT_ROWS: X rows may be missing too (a half-used block: 3C rows of the
-    // conditioned filter/gate gradient in two 128-row blocks); they borrow ap[0], which such
-    // an op guarantees to be a real row, and are zeroed at the LDS store (xzero)
+    // conditioned filter/gate gradient in two 128-row blocks); they borrow the first A row,
+    // which such an op guarantees to be a real row, and are zeroed at the LDS store (xzero)
     unsigned xzero_bits = 0;
 #pragma unroll
     for (int p = 0; p < 4 * NB; ++p) {
-      const int n = nblk * 64 * NB + 16 * p + srow;
+      const int n = nblk * 64 * NB + 16 * p + srow_q;
       const int lo = op.x_lo(n), hi = op.x_hi(n);
       const bool full = t0 >= lo && t0 + W2_T <= hi;
       const bool none = Op::X_ABSENT_ROWS && (t0 + W2_T <= lo || t0 >= hi);
@@ -427,34 +419,47 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
     const int t = t0 + st;
     azero = 0;
     xzero = 0;
+    // Row pointers are formed ONE AT A TIME, each right in front of its load, behind a
+    // scheduling fence: formed together (8 + 4 NB (+ 4 NB) 64-bit pointers next to 32 NB
+    // accumulators and the staging registers) they pushed the NB = 2 kernels well over the
+    // 256 registers a two-workgroup CU allows, and the spills landed in this loop.
     if (__all(inter)) {
       azero = zero_bits;
       xzero = xzero_bits;
-      // (xp[0] is valid over this tile -- every X row is; its index 0 need not be readable,
-      // so the masked path below keeps the row's own pointer)
+      // (x row 0 of this block is valid over this tile -- every X row is; its index 0 need not
+      // be readable, so the masked path below keeps the row's own pointer)
+      const float *x0p = op.x_ptr(b, nblk * 64 * NB + srow_q) + t;
+      const float *a0p = op.a_ptr(b, mblk * 128 + srow_q) + t;
 #pragma unroll
-      for (int p = 0; p < 8; ++p) areg[p] = ldg4((((zero_bits >> p) & 1u) ? xp[0] : ap[p]) + t);
+      for (int p = 0; p < 8; ++p) {
+        const float *q = ((zero_bits >> p) & 1u) ? x0p : op.a_ptr(b, mblk * 128 + 16 * p + srow_q) + t;
+        areg[p] = ldg4(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int p = 0; p < 4 * NB; ++p) {
-        xreg[p] = ldg4(((Op::X_ABSENT_ROWS && ((xzero_bits >> p) & 1u)) ? ap[0] : xp[p]) + t);
+        const bool absent = Op::X_ABSENT_ROWS && ((xzero_bits >> p) & 1u);
+        const float *q = absent ? a0p : op.x_ptr(b, nblk * 64 * NB + 16 * p + srow_q) + t;
+        xreg[p] = ldg4(q);
         if (Op::X_PRODUCT) {
-          const f4 v = ldg4(xq[p] + t);
+          const f4 v = ldg4(op.x_ptr2(b, nblk * 64 * NB + 16 * p + srow_q) + t);
           xreg[p] = f4{xreg[p].x * v.x, xreg[p].y * v.y, xreg[p].z * v.z, xreg[p].w * v.w};
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const int m = mblk * 128 + 16 * p + srow;
-        areg[p] = ld4_edge(ap[p], t, op.a_lo(m), min(op.a_hi(m), te));
+        const int m = mblk * 128 + 16 * p + srow_q;
+        areg[p] = ld4_edge(op.a_ptr(b, mblk * 128 + 16 * p + srow_q), t, op.a_lo(m), min(op.a_hi(m), te));
       }
 #pragma unroll
       for (int p = 0; p < 4 * NB; ++p) {
-        const int n = nblk * 64 * NB + 16 * p + srow;
+        const int n = nblk * 64 * NB + 16 * p + srow_q;
         const int lo = op.x_lo(n), hi = min(op.x_hi(n), te);
-        xreg[p] = ld4_edge(xp[p], t, lo, hi);
+        xreg[p] = ld4_edge(op.x_ptr(b, nblk * 64 * NB + 16 * p + srow_q), t, lo, hi);
         if (Op::X_PRODUCT) {
-          const f4 v = ld4_edge(xq[p], t, lo, hi);
+          const f4 v = ld4_edge(op.x_ptr2(b, nblk * 64 * NB + 16 * p + srow_q), t, lo, hi);
           xreg[p] = f4{xreg[p].x * v.x, xreg[p].y * v.y, xreg[p].z * v.z, xreg[p].w * v.w};
         }
       }
