@@ -304,21 +304,29 @@ def upsample_video(model, video: torch.Tensor) -> torch.Tensor:
     return _UpsampleVideoFunction.apply(model._dims, video, *[lookup[n] for n in VIDEO_PARAMS])
 
 
+def _decoder_params(model, with_context: bool):
+    L = model.layer_size * model.stack_size
+    names = decoder_param_names(L, with_context=with_context)
+    lookup = dict(model.named_parameters())
+    return names, [lookup[n] for n in names]
+
+
 def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalized: bool = True,
                     remove_last: bool = True) -> torch.Tensor:
     """WaveNet.forward.  NOTE the reference's inverted flag (wavenet.py:189-191):
     output_unnormalized=True returns PROBABILITIES.  ``context``: upsampled video
-    (B, C, T) or None."""
-    idx = model._indices_of(audio, strict=False)
-    if idx is None:  # not one-hot: dense causal conv on the tensor itself
-        idx = audio.detach().to(torch.float32).contiguous()
+    (B, C, T) or None.  One-hot input runs the causal conv as a gather; the check that the
+    input IS one-hot is read after the kernels have been enqueued (no host wait on an idle
+    GPU) and anything else is rerun through the dense causal conv."""
     model.compute_output_size(audio)  # ValueError when T < RF, like the reference
-    L = model.layer_size * model.stack_size
-    names = decoder_param_names(L, with_context=context is not None)
-    lookup = dict(model.named_parameters())
-    params = [lookup[n] for n in names]
+    idx, check = model._indices_async(audio)
+    names, params = _decoder_params(model, context is not None)
     out = _WaveNetFunction.apply(model._dims, names, idx, bool(output_unnormalized),
                                  bool(remove_last), context, *params)
+    if not model._all_one_hot(check):  # dense causal conv on the tensor itself
+        dense = audio.detach().to(torch.float32).contiguous()
+        out = _WaveNetFunction.apply(model._dims, names, dense, bool(output_unnormalized),
+                                     bool(remove_last), context, *params)
     return out if audio.dtype == torch.float32 else out.to(audio.dtype)
 
 
@@ -329,21 +337,17 @@ def wavenet_forward_loss(model, audio: torch.Tensor, context=None, target=None):
     the accuracy -- movenet/pytorch_lightning_trainer.py:62-66 -- with the softmax, the loss and
     the accuracy fused into one pass over the head's logits and their gradients into one pass
     back.  Same values as ``cross_entropy_on_probs(wavenet_forward(...), target)``."""
-    idx = model._indices_of(audio, strict=False)
-    rf = model.receptive_fields
-    if target is None:
-        if idx is None:
-            target = audio[:, :, rf:].argmax(1)
-        else:
-            target = idx[:, rf:].to(torch.int64)
-    if idx is None:
-        idx = audio.detach().to(torch.float32).contiguous()
     model.compute_output_size(audio)
-    L = model.layer_size * model.stack_size
-    names = decoder_param_names(L, with_context=context is not None)
-    lookup = dict(model.named_parameters())
-    params = [lookup[n] for n in names]
-    return _WaveNetLossFunction.apply(model._dims, names, idx, target, context, *params)
+    rf = model.receptive_fields
+    idx, check = model._indices_async(audio)
+    names, params = _decoder_params(model, context is not None)
+    tg = idx[:, rf:].to(torch.int64) if target is None else target
+    res = _WaveNetLossFunction.apply(model._dims, names, idx, tg, context, *params)
+    if not model._all_one_hot(check):  # (read after the enqueue: no idle GPU) dense causal conv
+        dense = audio.detach().to(torch.float32).contiguous()
+        tg = audio[:, :, rf:].argmax(1) if target is None else target
+        res = _WaveNetLossFunction.apply(model._dims, names, dense, tg, context, *params)
+    return res
 
 
 def mu_law_encode(x: torch.Tensor, quantization_channels: int) -> torch.Tensor:

@@ -139,10 +139,11 @@ class WaveNet(nn.Module):
         return out
 
     # ---- helpers --------------------------------------------------------
-    def _indices_of(self, audio: torch.Tensor, strict: bool = True):
-        """(B,Q,T) one-hot -> (B,T) int32 on device (mvn_onehot_to_index).  A column that
-        is not one-hot: ValueError when ``strict`` (generation works on class indices),
-        else None (forward then takes the dense causal-conv path)."""
+    def _indices_async(self, audio: torch.Tensor):
+        """(B,Q,T) one-hot -> ((B,T) int32 indices on device, 0-dim tensor = their minimum).
+        Nothing synchronises here: the minimum is -1 where a column is not exactly one-hot,
+        and the caller reads it (``.item()``) only AFTER it has enqueued the work that
+        assumes one-hot input, so the host never waits on an idle GPU."""
         _require_gpu(audio, "audio")
         if audio.dim() != 3 or audio.size(1) != self.input_channels:
             raise ValueError(f"audio must be (batch, {self.input_channels}, frames), "
@@ -153,7 +154,31 @@ class WaveNet(nn.Module):
         with torch.cuda.device(x.device):
             N.check(N.lib().mvn_onehot_to_index(x.data_ptr(), idx.data_ptr(), B, Q, T,
                                                 _stream_ptr(x.device)), "mvn_onehot_to_index")
-        if B * T and int(idx.min().item()) < 0:
+        low = idx.min() if B * T else torch.zeros((), dtype=torch.int32, device=x.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x.device))
+        return idx, (low, ready)
+
+    def _all_one_hot(self, check) -> bool:
+        """Read the minimum of ``_indices_async`` on a side stream that waits ONLY for the
+        kernels that produced it -- not for whatever the caller has enqueued since."""
+        low, ready = check
+        dev = low.device
+        side = self.__dict__.get("_check_stream")
+        if side is None or side.device != dev:
+            side = torch.cuda.Stream(device=dev)
+            self.__dict__["_check_stream"] = side
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            low.record_stream(side)
+            return int(low.item()) >= 0
+
+    def _indices_of(self, audio: torch.Tensor, strict: bool = True):
+        """(B,Q,T) one-hot -> (B,T) int32 on device (mvn_onehot_to_index).  A column that
+        is not one-hot: ValueError when ``strict`` (generation works on class indices),
+        else None (forward then takes the dense causal-conv path)."""
+        idx, check = self._indices_async(audio)
+        if not self._all_one_hot(check):
             if not strict:
                 return None
             raise ValueError(
