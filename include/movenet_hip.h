@@ -211,6 +211,18 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *params, const int32_t *i
                 int index_stride, int batch, int t_len, const mvn_fwd_buffers *buf, float *out,
                 int normalize, int remove_last, int save, void *stream);
 
+/* mvn_forward with FP16 OPERANDS and FP32 ACCUMULATION in every product of the layers and
+ * the head (BASELINE configs[4] "fp16 MFMA 1x1 convs"; reference precedent for reduced
+ * precision: torch.autocast, movenet/trainer.py:124): weights and the activations entering a
+ * product are rounded to fp16 as they are staged, multiplied by v_mfma_f32_32x32x16_f16 and
+ * summed in fp32; the causal conv's gather, biases, gating, residual adds, the skip sum, the
+ * softmax and every tensor in HBM stay fp32 -- the rounding points of MVN_GEN_PIPE_F16.  Same
+ * arguments and buffers as mvn_forward; `save` keeps th/sg/acts, but mvn_backward
+ * differentiates the fp32 forward: train in fp32 (the default). */
+int mvn_forward_f16(const mvn_dims *dims, const mvn_params *params, const int32_t *index,
+                    int index_stride, int batch, int t_len, const mvn_fwd_buffers *buf, float *out,
+                    int normalize, int remove_last, int save, void *stream);
+
 /* Gradients, same layouts as mvn_params (members may not be NULL except ctx_*);
  * mvn_backward ACCUMULATES into them (zero them first for a fresh gradient). */
 typedef struct mvn_param_grads {

@@ -110,6 +110,9 @@ SIGNATURES = {
     "mvn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.POINTER(FwdBuffers), C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.c_void_p]),
+    "mvn_forward_f16": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.POINTER(FwdBuffers), C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
     "mvn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(ParamGrads),
                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FwdBuffers),
                                C.POINTER(BwdBuffers), C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -212,6 +212,121 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_staged_kernel(Op op) {
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// The same product with FP16 OPERANDS and FP32 ACCUMULATION (BASELINE configs[4]; precedent:
+// torch.autocast, movenet/trainer.py:124): W and X are rounded to fp16 (nearest even) when they
+// are stored to LDS -- after Op::x's own element-wise map (leaky-ReLU ...), i.e. exactly the
+// operands the fp16 generator kernel rounds -- and multiplied by v_mfma_f32_32x32x16_f16; the
+// accumulators, the epilogue (bias, gate, residual add, skip accumulation) and every tensor
+// in HBM stay fp32.  One MFMA per 16-deep k-chunk and tile instead of eight: the kernel is
+// bound by its load path.  LDS tiles are k-contiguous ([row][16 halves], pitch 48 bytes: a
+// lane's 8 operands are one ds_read_b128), X is transposed on the way in (a thread holds the
+// 16 k of its own column).
+// ----------------------------------------------------------------------------------------
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+constexpr int GXH_PITCH = 24;  // halves per LDS row (16 used): 48 bytes keeps ds_read_b128 aligned and spreads banks
+
+template <class Op>
+__global__ __launch_bounds__(256, 2) void gemm_wx_staged_f16_kernel(Op op) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * GXH_PITCH * 2 + 32 * 256 * 4];
+  _Float16 *Wh = (_Float16 *)lds;                                   // [2][64][GXH_PITCH]
+  _Float16 *Xh = (_Float16 *)(lds + 2 * 64 * GXH_PITCH * 2);       // [2][256][GXH_PITCH] (24 KB)
+  float *stage = (float *)(lds + 2 * 64 * GXH_PITCH * 2);           // [32][256] floats (32 KB), epilogue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, mb = blockIdx.y;
+  const int t0 = (op.t_begin & ~3) + blockIdx.x * 256;
+  const int nchunk = (op.K + GX_KC - 1) / GX_KC;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float wreg[4], xreg[16];
+  auto gload = [&](int c) {
+    const int k0 = c * GX_KC;
+    // thread -> W row (tid >> 2), k quarter (tid & 3): four consecutive k
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wreg[j] = op.w(mb * 64 + (tid >> 2), k0 + 4 * (tid & 3) + j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xreg[j] = op.x(b, k0 + j, t0 + tid);
+  };
+  auto lstore = [&](int buf) {
+    typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+    *(hf4 *)&Wh[(buf * 64 + (tid >> 2)) * GXH_PITCH + 4 * (tid & 3)] =
+        hf4{(_Float16)wreg[0], (_Float16)wreg[1], (_Float16)wreg[2], (_Float16)wreg[3]};
+    hf8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      lo[j] = (_Float16)xreg[j];
+      hi[j] = (_Float16)xreg[8 + j];
+    }
+    *(hf8 *)&Xh[(buf * 256 + tid) * GXH_PITCH] = lo;
+    *(hf8 *)&Xh[(buf * 256 + tid) * GXH_PITCH + 8] = hi;
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int li = lane & 31, kg = 8 * (lane >> 5);
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload(c + 1);
+    const hf8 a0 = *(const hf8 *)&Wh[(buf * 64 + li) * GXH_PITCH + kg];
+    const hf8 a1 = *(const hf8 *)&Wh[(buf * 64 + 32 + li) * GXH_PITCH + kg];
+    const hf8 b0 = *(const hf8 *)&Xh[(buf * 256 + 64 * wave + li) * GXH_PITCH + kg];
+    const hf8 b1 = *(const hf8 *)&Xh[(buf * 256 + 64 * wave + 32 + li) * GXH_PITCH + kg];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: identical to gemm_wx_staged_kernel (fp32 accumulators through a 32 x 256 stage)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[acc_row(r, lane) * 256 + 64 * wave + 32 * ni + (lane & 31)] = acc[mi][ni][r];
+    __syncthreads();
+    const int c4 = tid & 63, t = t0 + 4 * c4;
+    if constexpr (Op::FG_PAIRS) {
+      if (t < op.t_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wave + 4 * j;
+          op.store_fg(b, mb * 32 + 16 * mi + row, t, *(const f4 *)&stage[row * 256 + 4 * c4],
+                      *(const f4 *)&stage[(16 + row) * 256 + 4 * c4]);
+        }
+      }
+    } else if (t < op.t_end) {
+      constexpr int EB = Op::EPI_BATCH;
+#pragma unroll
+      for (int j0 = 0; j0 < 8; j0 += EB) {
+        f4 v[EB];
+        typename Op::Pre pre[EB];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+          const int row = wave + 4 * (j0 + j);
+          v[j] = *(const f4 *)&stage[row * 256 + 4 * c4];
+          pre[j] = op.load4(b, mb * 64 + 32 * mi + row, t);
+        }
+#pragma unroll
+        for (int j = 0; j < EB; ++j)
+          op.store4(b, mb * 64 + 32 * mi + wave + 4 * (j0 + j), t, v[j], pre[j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // column mask helpers for store4: all four columns inside [lo, hi)?
 __device__ __forceinline__ bool cols_full(int t, int lo, int hi) { return t >= lo && t + 3 < hi; }
 struct Pre1 { f4 a; };     // operands preloaded for one store4 (see gemm_wx_staged_kernel)
@@ -610,6 +725,16 @@ static void launch_gemm_staged(const Op &op, int m_rows, int batch, hipStream_t 
   if (op.t_end <= op.t_begin || batch <= 0) return;
   dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
   hipLaunchKernelGGL(gemm_wx_staged_kernel<Op>, grid, dim3(256), 0, s, op);
+}
+
+// `f16`: the fp16-operand / fp32-accumulate form (inference: mvn_forward_f16)
+template <class Op>
+static void launch_gemm_staged(const Op &op, int m_rows, int batch, hipStream_t s, bool f16) {
+  if (!f16) return launch_gemm_staged(op, m_rows, batch, s);
+  const int nt = op.t_end - (op.t_begin & ~3);
+  if (op.t_end <= op.t_begin || batch <= 0) return;
+  dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
+  hipLaunchKernelGGL(gemm_wx_staged_f16_kernel<Op>, grid, dim3(256), 0, s, op);
 }
 
 template <class Op>

@@ -781,9 +781,9 @@ extern "C" {
 
 int mvn_padded_len(int n) { return n <= 0 ? 0 : (n + 63) / 64 * 64; }
 
-int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index, int index_stride,
-                int batch, int t_len, const mvn_fwd_buffers *buf, float *out, int normalize,
-                int remove_last, int save, void *stream_) {
+static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t *index, int index_stride,
+                        int batch, int t_len, const mvn_fwd_buffers *buf, float *out, int normalize,
+                        int remove_last, int save, void *stream_, bool f16) {
   Geometry g;
   int rc = make_geometry(dims, batch, t_len, g);
   if (rc) return rc;
@@ -838,7 +838,7 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
       f.xin = xin; f.z = zv;
       f.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
       f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
-      launch_gemm_staged(f, 2 * ((C + 31) / 32 * 32), batch, s);
+      launch_gemm_staged(f, 2 * ((C + 31) / 32 * 32), batch, s, f16);
     };
     if (has_ctx) run_fg(FgOpT<true>()); else run_fg(FgOpT<false>());
     RsOp r;
@@ -847,7 +847,7 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     r.wr = p->residual_w[l]; r.br = p->residual_b[l]; r.ws = p->skip_w[l]; r.bs = p->skip_b[l];
     r.z = zv; r.xin = xin; r.xout = xout; r.skip = skipv; r.first_layer = (l == 0);
     if (l == g.L - 1) r.xout.p = nullptr;  // the last residual output is never used
-    launch_gemm_staged(r, C + Kc, batch, s);
+    launch_gemm_staged(r, C + Kc, batch, s, f16);
     A += d;
   }
   // head: a1 = lrelu(W1 lrelu(skip) + b1); logits = W2 a1 + b2   (columns s = 0..S-1)
@@ -857,7 +857,7 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     h1.K = Kc; h1.t_begin = g.pad; h1.t_end = g.pad + g.S; h1.M = Q; h1.wmat = p->head1_w;
     h1.ldw = Kc; h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v;
     h1.t_out_end = g.pad + g.S; h1.aligned_out = 1;
-    launch_gemm_staged(h1, Q, batch, s);
+    launch_gemm_staged(h1, Q, batch, s, f16);
   }
   if (S_out > 0) {
     DenseOp<IN_ID, OUT_BIAS, false> h2;
@@ -866,7 +866,7 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     // `out` is the caller's contiguous (B, Q, S_out): column s of the head = out column s - pad
     h2.yout = act_view(out - g.pad, batch, Q, S_out);
     h2.t_out_end = g.pad + S_out; h2.aligned_out = 0;
-    launch_gemm_staged(h2, Q, batch, s);
+    launch_gemm_staged(h2, Q, batch, s, f16);
     if (normalize) {
       if (Q <= 4 * CQ)
         hipLaunchKernelGGL(softmax_cols_kernel, dim3((S_out + 63) / 64, batch), dim3(256), 0, s, out, Q,
@@ -877,6 +877,20 @@ int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index,
     }
   }
   return check_hip(hipGetLastError(), "mvn_forward");
+}
+
+int mvn_forward(const mvn_dims *dims, const mvn_params *p, const int32_t *index, int index_stride,
+                int batch, int t_len, const mvn_fwd_buffers *buf, float *out, int normalize,
+                int remove_last, int save, void *stream_) {
+  return forward_impl(dims, p, index, index_stride, batch, t_len, buf, out, normalize, remove_last, save, stream_,
+                      false);
+}
+
+int mvn_forward_f16(const mvn_dims *dims, const mvn_params *p, const int32_t *index, int index_stride,
+                    int batch, int t_len, const mvn_fwd_buffers *buf, float *out, int normalize,
+                    int remove_last, int save, void *stream_) {
+  return forward_impl(dims, p, index, index_stride, batch, t_len, buf, out, normalize, remove_last, save, stream_,
+                      true);
 }
 
 int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grads *gr,

@@ -129,9 +129,8 @@ class RingGenerator:
         self.t = 0          # number of time steps consumed so far
         self.n_given = 1
         # queues primed by one full-sequence forward (MFMA kernels) instead of stepping; the
-        # forward kernels compute in fp32, so the fp16-operand variant steps over the prompt
-        # itself to keep ONE arithmetic from the first sample on
-        self.prime_with_forward = self.variant != N.GEN_PIPE_F16
+        # fp16-operand variant primes with the fp16-operand forward: ONE arithmetic throughout
+        self.prime_with_forward = True
         self.repack(state_dict)
 
     def repack(self, state_dict: Dict[str, torch.Tensor]) -> None:
@@ -199,7 +198,8 @@ class RingGenerator:
             from .ops import run_forward
             idx = self.samples[:, :P].contiguous()
             ctx = None if self.context is None else self.context[:, :, :P]
-            _, buf = run_forward(self.dims, self._sd, idx, False, False, save=True, ctx=ctx)
+            _, buf = run_forward(self.dims, self._sd, idx, False, False, save=True, ctx=ctx,
+                                 f16=self.variant == N.GEN_PIPE_F16)
             with torch.cuda.device(self.device):
                 N.check(self.lib.mvn_gen_prime_from_forward(
                     self.dims, buf.struct, self.batch, P, self.state.data_ptr(),

@@ -68,9 +68,10 @@ class ForwardBuffers:
 
 
 def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, normalize: bool,
-                remove_last: bool, save: bool, ctx=None) -> Tuple[torch.Tensor, ForwardBuffers]:
+                remove_last: bool, save: bool, ctx=None, f16: bool = False) -> Tuple[torch.Tensor, ForwardBuffers]:
     """idx: (B,T) int32 class indices, or a (B,Q,T) fp32 tensor for inputs that are
-    not one-hot (dense causal conv)."""
+    not one-hot (dense causal conv).  ``f16``: fp16 operands / fp32 accumulation in every
+    product (mvn_forward_f16; inference and generator priming)."""
     lib = N.lib()
     _require_gpu(idx, "audio")
     dense = None
@@ -92,10 +93,11 @@ def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, no
         s_out = buf.S - (1 if remove_last else 0)
         out = torch.empty((B, dims.input_channels, max(s_out, 0)), dtype=torch.float32, device=dev)
         params, keep = pack_params(dims, sd, L)
-        N.check(lib.mvn_forward(dims, params, None if dense is not None else idx.data_ptr(),
-                                0 if dense is not None else idx.stride(0), B, T, buf.struct,
-                                out.data_ptr(), int(normalize), int(remove_last), int(save),
-                                _stream_ptr(dev)), "mvn_forward")
+        fwd = lib.mvn_forward_f16 if f16 else lib.mvn_forward
+        N.check(fwd(dims, params, None if dense is not None else idx.data_ptr(),
+                    0 if dense is not None else idx.stride(0), B, T, buf.struct,
+                    out.data_ptr(), int(normalize), int(remove_last), int(save),
+                    _stream_ptr(dev)), "mvn_forward_f16" if f16 else "mvn_forward")
     buf._keep = keep  # parameter tensors stay alive until the kernels have run
     return out, buf
 
@@ -108,7 +110,11 @@ class _WaveNetFunction(torch.autograd.Function):
     def forward(ctx_, dims, names, idx, normalize, remove_last, context, *params):
         sd = dict(zip(names, params))
         save = any(ctx_.needs_input_grad[5:])  # grad mode itself is off inside forward()
-        out, buf = run_forward(dims, sd, idx, normalize, remove_last, save, context)
+        f16 = bool(getattr(dims, "_f16", False))
+        if f16 and save:
+            raise RuntimeError("movenet_amd: forward_precision 'fp16' is inference-only "
+                               "(mvn_backward differentiates the fp32 forward); use torch.no_grad()")
+        out, buf = run_forward(dims, sd, idx, normalize, remove_last, save, context, f16=f16)
         ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf = dims, names, idx, buf
         ctx_.normalize, ctx_.remove_last, ctx_.saved_fwd = normalize, remove_last, save
         ctx_.has_context = context is not None
@@ -321,11 +327,16 @@ def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalize
     model.compute_output_size(audio)  # ValueError when T < RF, like the reference
     idx, check = model._indices_async(audio)
     names, params = _decoder_params(model, context is not None)
-    out = _WaveNetFunction.apply(model._dims, names, idx, bool(output_unnormalized),
+    dims = model._dims
+    if model.forward_precision == "fp16":  # a tagged copy: the autograd Function reads the flag
+        dims = N.make_dims(dims.layer_size, dims.stack_size, dims.input_channels, dims.residual_channels,
+                           dims.skip_channels)
+        dims._f16 = True
+    out = _WaveNetFunction.apply(dims, names, idx, bool(output_unnormalized),
                                  bool(remove_last), context, *params)
     if not model._all_one_hot(check):  # dense causal conv on the tensor itself
         dense = audio.detach().to(torch.float32).contiguous()
-        out = _WaveNetFunction.apply(model._dims, names, dense, bool(output_unnormalized),
+        out = _WaveNetFunction.apply(dims, names, dense, bool(output_unnormalized),
                                      bool(remove_last), context, *params)
     return out if audio.dtype == torch.float32 else out.to(audio.dtype)
 

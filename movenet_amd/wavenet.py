@@ -102,6 +102,9 @@ class WaveNet(nn.Module):
         self._dims = N.make_dims(layer_size, stack_size, Q, C, K)
         self._gen_variant = N.GEN_AUTO
         self.last_generate_fallback = None  # variant a timed-out PIPE call was rerun on
+        # "fp32" (default) or "fp16": fp16 operands / fp32 accumulation in every product of
+        # forward() (mvn_forward_f16, any dims; inference only -- training stays fp32)
+        self.forward_precision = "fp32"
 
     # ---- precision of generate() ----------------------------------------
     @property

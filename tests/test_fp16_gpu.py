@@ -51,7 +51,7 @@ def test_fp16_generator_logits_within_tolerance(cfg, B, n_new):
     c16, l16 = ring_c.generate_ring_c(sd, dims, hist.numpy()[:, :rf], rf + n_new, forced_idx=hist.numpy(), threads=4,
                                       operand_dtype=np.float16)
     g = _gen(cfg, sd, B, rf + n_new, N.GEN_PIPE_F16)
-    assert g.variant == N.GEN_PIPE_F16 and not g.prime_with_forward
+    assert g.variant == N.GEN_PIPE_F16
     choices, logits = g.teacher_forced(hist.to(DEV), logits_t0=rf)
     g.check_errors()
     logits, choices = logits.cpu().numpy(), choices[:, rf:].cpu().numpy()
@@ -120,3 +120,54 @@ def test_fp16_capacity_one_xcd():
     d5 = N.make_dims(10, 6, 256, 128, 128)
     assert max_pipe_batch(d5, N.GEN_PIPE) == 4 and max_pipe_batch(d5, N.GEN_PIPE_F16) == 8
     assert N.lib().mvn_gen_variant(d5, N.GEN_AUTO, 1) == N.GEN_PIPE  # fp32 stays the default
+
+
+def test_fp16_forward_mfma_within_tolerance(golden):
+    """mvn_forward_f16 (v_mfma_f32_32x32x16_f16 operands, fp32 accumulation) against the
+    reference's own fp32 logits of the 60-layer, 128-channel model (fixture G6, recorded from
+    movenet's WaveNet.forward as the yard-stick of this tolerance), against this build's fp32
+    forward, and against the fp16 generator stepping over the same history (same rounding
+    points, different summation order)."""
+    from helpers import rel_err, weights_of
+    from movenet_amd.wavenet import WaveNet
+    fx = golden("g6_l60_forward.npz")
+    cfg, dims, sd = weights_of(fx)
+    T = int(fx["T"])
+    hist = synthetic_indices(1, T, 256, int(fx["idx_seed"]))
+    x = one_hot(hist, 256).to(DEV)
+    m = WaveNet(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    with torch.no_grad():
+        l32 = m(x, output_unnormalized=False, remove_last=False)
+        m.forward_precision = "fp16"
+        l16 = m(x, output_unnormalized=False, remove_last=False)
+        p16 = m(x)
+    scale = float(np.abs(fx["logits"]).max())
+    e_ref = np.abs(l16.cpu().numpy() - fx["logits"]).max() / scale
+    e_own = (l16 - l32).abs().max().item() / scale
+    print(f"fp16 forward: {e_ref:.2e} of the logit range from the reference's fp32 logits (G6), {e_own:.2e} from "
+          f"this build's fp32 forward")
+    assert e_ref < FP16_TOL and e_own < FP16_TOL and e_own > 1e-6
+    assert (p16.sum(1) - 1).abs().max().item() < 1e-5
+    with pytest.raises(RuntimeError):   # inference only
+        m(x).sum().backward()
+    # the fp16 generator, primed by this forward and teacher-forced over the same history
+    rf = dims.receptive_fields
+    g = _gen(cfg, sd, 1, T, N.GEN_PIPE_F16)
+    _, lg = g.teacher_forced(hist.to(DEV), logits_t0=rf)
+    g.check_errors()
+    want = l16[:, :, :-1].permute(0, 2, 1)   # (B, T - rf, Q): predicts times rf .. T-1
+    assert (lg - want).abs().max().item() / scale < FP16_TOL
+    # small model, every dims path of the kernel family (C = 16: padded rows / k)
+    cfg1 = dict(layer_size=3, stack_size=2, input_channels=64, residual_channels=16, skip_channels=16)
+    sd1 = make_state_dict(**cfg1, seed=7, gain=2.0, head_gain=4.0)
+    m1 = WaveNet(**cfg1)
+    m1.load_state_dict(sd1, strict=True)
+    m1.to(DEV)
+    x1 = one_hot(synthetic_indices(2, 300, 64, 3), 64).to(DEV)
+    with torch.no_grad():
+        a = m1(x1, output_unnormalized=False)
+        m1.forward_precision = "fp16"
+        b = m1(x1, output_unnormalized=False)
+    assert 1e-7 < (a - b).abs().max().item() / a.abs().max().item() < FP16_TOL
