@@ -109,7 +109,8 @@ class _WaveNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, dims, names, idx, normalize, remove_last, context, *params):
         sd = dict(zip(names, params))
-        save = any(ctx_.needs_input_grad[5:])  # grad mode itself is off inside forward()
+        # (grad mode itself is off inside forward(): the caller records whether it was on)
+        save = any(ctx_.needs_input_grad[5:]) and bool(getattr(dims, "_grad_mode", True))
         f16 = bool(getattr(dims, "_f16", False))
         if f16 and save:
             raise RuntimeError("movenet_amd: forward_precision 'fp16' is inference-only "
@@ -207,7 +208,7 @@ class _WaveNetLossFunction(torch.autograd.Function):
     def forward(ctx_, dims, names, idx, target, context, *params):
         lib = N.lib()
         sd = dict(zip(names, params))
-        save = any(ctx_.needs_input_grad[4:])
+        save = any(ctx_.needs_input_grad[4:]) and bool(getattr(dims, "_grad_mode", True))
         out, buf = run_forward(dims, sd, idx, False, True, save, context)  # logits, last column dropped
         B, Q, S = out.shape
         if target.shape != (B, S):
@@ -310,6 +311,16 @@ def upsample_video(model, video: torch.Tensor) -> torch.Tensor:
     return _UpsampleVideoFunction.apply(model._dims, video, *[lookup[n] for n in VIDEO_PARAMS])
 
 
+def _tagged_dims(dims, f16: bool = False):
+    """A copy of the dims struct carrying what the autograd Functions cannot see from inside
+    ``forward``: whether grad mode was on at the call, and the operand precision."""
+    d = N.make_dims(dims.layer_size, dims.stack_size, dims.input_channels, dims.residual_channels,
+                    dims.skip_channels)
+    d._grad_mode = torch.is_grad_enabled()
+    d._f16 = f16
+    return d
+
+
 def _decoder_params(model, with_context: bool):
     L = model.layer_size * model.stack_size
     names = decoder_param_names(L, with_context=with_context)
@@ -327,11 +338,7 @@ def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalize
     model.compute_output_size(audio)  # ValueError when T < RF, like the reference
     idx, check = model._indices_async(audio)
     names, params = _decoder_params(model, context is not None)
-    dims = model._dims
-    if model.forward_precision == "fp16":  # a tagged copy: the autograd Function reads the flag
-        dims = N.make_dims(dims.layer_size, dims.stack_size, dims.input_channels, dims.residual_channels,
-                           dims.skip_channels)
-        dims._f16 = True
+    dims = _tagged_dims(model._dims, f16=model.forward_precision == "fp16")
     out = _WaveNetFunction.apply(dims, names, idx, bool(output_unnormalized),
                                  bool(remove_last), context, *params)
     if not model._all_one_hot(check):  # dense causal conv on the tensor itself
@@ -353,11 +360,12 @@ def wavenet_forward_loss(model, audio: torch.Tensor, context=None, target=None):
     idx, check = model._indices_async(audio)
     names, params = _decoder_params(model, context is not None)
     tg = idx[:, rf:].to(torch.int64) if target is None else target
-    res = _WaveNetLossFunction.apply(model._dims, names, idx, tg, context, *params)
+    dims = _tagged_dims(model._dims)
+    res = _WaveNetLossFunction.apply(dims, names, idx, tg, context, *params)
     if not model._all_one_hot(check):  # (read after the enqueue: no idle GPU) dense causal conv
         dense = audio.detach().to(torch.float32).contiguous()
         tg = audio[:, :, rf:].argmax(1) if target is None else target
-        res = _WaveNetLossFunction.apply(model._dims, names, dense, tg, context, *params)
+        res = _WaveNetLossFunction.apply(dims, names, dense, tg, context, *params)
     return res
 
 
