@@ -41,8 +41,9 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (vector)" = "Peak FP
 # HBM-side bytes per generated sample per sequence of gen_pipe_kernel<64>, from separate
 # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an earlier run of this same command; NOT
 # measured by the run that prints the line (roofline.traffic_source says so)
-PMC_TRAFFIC = {"bytes_per_step_seq": (19810.6 + 14644.8) * 1024 / (16 * 16000),
-               "source": "profiles/r01b_pmc_gen_pipe_fetch_write.csv"}
+PMC_TRAFFIC = {"bytes_per_step_seq": (19812.3 + 13884.6) * 1024 / (16 * 16000),
+               "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19812 KiB + WRITE_SIZE "
+                         "13885 KiB per 16000-step launch of 16 sequences)"}
 
 
 def flop_per_sample(cfg) -> int:
@@ -274,7 +275,10 @@ def extra_lines(dev, sd, rf, n_new, rank):
     model.load_state_dict(make_state_dict(**CFG, seed=0))
     model.to(dev)
     audio = one_hot(prompt, CFG["input_channels"])
-    model.generate(audio, n_samples=rf + 64, temperature=0.0)  # code objects, allocator
+    # (warm-up at FULL length: every launch of the generator kernel in this process then has the
+    # same step count, so the kernel's average in a rocprofv3 --stats run of this command is the
+    # per-launch time the roofline line quotes)
+    model.generate(audio, n_samples=rf + n_new, temperature=0.0)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     y = model.generate(audio, n_samples=rf + n_new, temperature=0.0)
