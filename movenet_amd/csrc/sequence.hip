@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "gemm_family.h"
+#include "fused_layer.h"
 
 namespace mvn {
 
@@ -840,6 +841,32 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       f.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
       launch_gemm_staged(f, 2 * ((C + 31) / 32 * 32), batch, s, f16);
     };
+    // C = K = 64, audio only, fp32: the layer as ONE kernel (fused_layer.h); same bits as the
+    // two-kernel form below (MOVENET_HIP_NO_FUSED_FORWARD=1 keeps the latter: A/B and tests)
+    static const bool no_fused = [] {
+      const char *e = getenv("MOVENET_HIP_NO_FUSED_FORWARD");
+      return e && e[0] == '1';
+    }();
+    // (the layer's weights are re-packed k-major into the z scratch, which this path never
+    // touches otherwise: z stays in LDS)
+    if (C == FL_C && Kc == FL_C && !has_ctx && !f16 && !no_fused && (size_t)g.act >= (size_t)g.L * FL_PACK_F) {
+      if (l == 0)
+        for (int ll = 0; ll < g.L; ++ll)
+          hipLaunchKernelGGL(fused_pack_kernel, dim3((FL_PACK_F + 255) / 256), dim3(256), 0, s, p->filter_w[ll],
+                             p->gate_w[ll], p->residual_w[ll], p->skip_w[ll], buf->z + (size_t)ll * FL_PACK_F);
+      FusedLayerArgs fa;
+      fa.t_begin = A + d; fa.t_end = T; fa.d = d; fa.t_skip0 = t_skip0; fa.t_base = g.t_base;
+      fa.first_layer = (l == 0);
+      fa.wpack = buf->z + (size_t)l * FL_PACK_F;
+      fa.br = p->residual_b[l]; fa.bs = p->skip_b[l];
+      fa.xin = xin; fa.xout = xout; fa.skip = skipv;
+      if (l == g.L - 1) fa.xout.p = nullptr;  // the last residual output is never used
+      fa.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+      fa.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+      launch_fused_layer64(fa, batch, s);
+      A += d;
+      continue;
+    }
     if (has_ctx) run_fg(FgOpT<true>()); else run_fg(FgOpT<false>());
     RsOp r;
     r.K = C; r.t_begin = A + d; r.t_end = T; r.C = C; r.Kc = Kc; r.t_skip0 = t_skip0;
