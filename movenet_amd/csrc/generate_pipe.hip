@@ -202,16 +202,24 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
 
     for (int ts = a.t_begin; ts < a.t_end; ++ts) {
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      // C = 64: the step starts as soon as the 64 residual-stream granules are in; the running
+      // skip sum (sent a little later by the producer, see below) is awaited by wave 4 while
+      // the filter/gate waves already work on the first layer.  C = 128: one wait for both.
+      constexpr bool SPLIT = CC == 64;
       if (wave == 0) {
-        float v[GL];
-        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
-        if (ok) {
-          // granules 0..C-1 residual stream, C..2C-1 running skip sum
-          if (GL == 2) {
-            float *dst = lane < 32 ? cur + 2 * lane : skin + 2 * (lane - 32);
-            dst[0] = v[0];
-            dst[1] = v[1];
-          } else {
+        bool ok;
+        if constexpr (SPLIT) {
+          float v[2];
+          ok = wait_inbox64(inbox, epoch, err, v);
+          if (ok && lane < 32) {
+            cur[2 * lane] = v[0];
+            cur[2 * lane + 1] = v[1];
+          }
+        } else {
+          float v[GL];
+          ok = wait_inbox<GL>(inbox, epoch, err, v);
+          if (ok) {
+            // granules 0..C-1 residual stream, C..2C-1 running skip sum
             cur[2 * lane] = v[0];
             cur[2 * lane + 1] = v[1];
             skin[2 * lane] = v[GL - 2];
@@ -222,7 +230,19 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
-      float skipacc = (!fg_group && lead) ? skin[c] : 0.f;
+      if constexpr (SPLIT) {
+        if (wave == 4) {  // off the chain: the residual/skip waves idle during the first f/g phase
+          float v[2];
+          const bool ok = wait_inbox64(inbox + C, epoch, err, v);
+          if (ok && lane < 32) {
+            skin[2 * lane] = v[0];
+            skin[2 * lane + 1] = v[1];
+          }
+          if (lane == 0) iflag[1] = ok ? 1 : 0;
+        }
+      }
+      float skipacc = 0.f;
+      if constexpr (!SPLIT) skipacc = (!fg_group && lead) ? skin[c] : 0.f;
 #pragma unroll
       for (int j = 0; j < LPS; ++j)
         if (j < nl) {
@@ -244,31 +264,62 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
             old = cur[c];  // this layer's input: residual add below, queue push later
           }
           lds_barrier();
-          if (!fg_group) {
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 256);
-            float r, k;
-            dot2_lds<NF4>(wa[j], wb[j], zb + KPER * kq, r, k);
-            r = chan_sum<KQ>(r);
-            k = chan_sum<KQ>(k);
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 256);
-            if (lead) {
-              xs[j] = old;
-              const float outv = (r + bias_r[j]) + old;
-              cur[c] = outv;
-              skipacc += k + bias_s[j];
-              if (j == nl - 1) {
-                // the stage's last layer: hand the activation on before anything else
-                put_granule(outbox + c, epoch, outv, fast_edge);
-                put_granule(outbox + C + c, epoch, skipacc, fast_edge);
+          if constexpr (SPLIT) {
+            // Only the residual row is on the chain: it is finished and published first; the
+            // skip row (same z, kept in registers) follows behind the barrier, while the
+            // filter/gate waves are already on the next layer.
+            f4 xz[NF4];
+            if (!fg_group) {
+              if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 256);
+              if (j == 0 && lead) skipacc = skin[c];  // wave 4 stored it before this barrier
+              ldsn<NF4>(xz, zb + KPER * kq);
+              const float r = chan_sum<KQ>(dotn<NF4>(wa[j], xz));
+              if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 256);
+              if (lead) {
+                xs[j] = old;
+                const float outv = (r + bias_r[j]) + old;
+                cur[c] = outv;
+                if (j == nl - 1) put_granule(outbox + c, epoch, outv, fast_edge);  // hand on at once
+              }
+              if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 4, 256);
+            }
+            lds_barrier();
+            if (!fg_group) {
+              const float k = chan_sum<KQ>(dotn<NF4>(wb[j], xz));
+              if (lead) {
+                skipacc += k + bias_s[j];
+                if (j == nl - 1) put_granule(outbox + C + c, epoch, skipacc, fast_edge);
               }
             }
-            if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 4, 256);
+          } else {
+            if (!fg_group) {
+              float r, k;
+              dot2_lds<NF4>(wa[j], wb[j], zb + KPER * kq, r, k);
+              r = chan_sum<KQ>(r);
+              k = chan_sum<KQ>(k);
+              if (lead) {
+                xs[j] = old;
+                const float outv = (r + bias_r[j]) + old;
+                cur[c] = outv;
+                skipacc += k + bias_s[j];
+                if (j == nl - 1) {
+                  // the stage's last layer: hand the activation on before anything else
+                  put_granule(outbox + c, epoch, outv, fast_edge);
+                  put_granule(outbox + C + c, epoch, skipacc, fast_edge);
+                }
+              }
+            }
+            lds_barrier();
           }
-          lds_barrier();
           if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 5, 0);
         }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
-      if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      if constexpr (SPLIT) {
+        // (iflag[1] was written by wave 4 before the first f/g -> r/s barrier of this step)
+        if (iflag[0] == 0 || iflag[1] == 0) break;
+      } else {
+        if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      }
       if (ts + 1 < a.t_end) {
         precompute(ts + 1, true);
       } else if (!fg_group && lead) {

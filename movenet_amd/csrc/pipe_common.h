@@ -96,6 +96,31 @@ __device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsign
   }
 }
 
+// 64 granules (512 bytes) of an inbox: lanes 0-31 take two each with one 16-byte load (lanes
+// 32-63 repeat them).  v[0], v[1] = granules 2 (lane & 31), + 1 of `in`.  Wave-uniform result.
+__device__ __forceinline__ bool wait_inbox64(const u64 *in, unsigned epoch, unsigned *err, float (&v)[2]) {
+  const int lane = threadIdx.x & 63;
+  const u64 *p = in + 2 * (lane & 31);
+  for (unsigned spins = 1;; ++spins) {
+    v4u g0;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g0) : "v"(p) : "memory");
+    const bool ok = g0.y == epoch && g0.w == epoch;
+    if (__all(ok)) {
+      v[0] = __uint_as_float(g0.x);
+      v[1] = __uint_as_float(g0.z);
+      return true;
+    }
+    if ((spins & 255u) == 0) {
+      const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // ---- cross-lane moves as DPP (one VALU op) instead of ds_bpermute (an LDS round trip)
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
