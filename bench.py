@@ -41,9 +41,9 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (vector)" = "Peak FP
 # HBM-side bytes per generated sample per sequence of gen_pipe_kernel<64>, from separate
 # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an earlier run of this same command; NOT
 # measured by the run that prints the line (roofline.traffic_source says so)
-PMC_TRAFFIC = {"bytes_per_step_seq": (19812.3 + 13884.6) * 1024 / (16 * 16000),
-               "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19812 KiB + WRITE_SIZE "
-                         "13885 KiB per 16000-step launch of 16 sequences)"}
+PMC_TRAFFIC = {"bytes_per_step_seq": (19818.3 + 15008.8) * 1024 / (16 * 16000),
+               "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19818 KiB + WRITE_SIZE "
+                         "15009 KiB per 16000-step launch of 16 sequences)"}
 
 
 def flop_per_sample(cfg) -> int:
