@@ -13,19 +13,20 @@
 //
 // A stage holds THREE layers (10 layer stages + the head = 11 workgroups per sequence).  Its
 // inbox carries 3C granules {xp, zl, sk}: xp = the stream WITHOUT the previous stage's last
-// residual term, zl = that stage's last gated activation, sk = the running skip sum without
-// the previous stage's last layer.  Waves 0-3 (the chain) compute
+// residual term, zl = that stage's last gated activation -- the two the chain waits for -- and
+// sk = the running skip sum, which travels on a lane of its own (sent and awaited off the chain,
+// after the stage's third phase).  Waves 0-3 (the chain) compute
 //     z_0 = gate(Wc_0 xp + (Wc_0 Wr_prev) zl + pf_0)
-//     z_1 = gate((Wc_1 Wr_0) z_0 + base_1 + pf_1)
-//     z_2 = gate((Wc_2 Wr_1) z_1 + base_2 + pf_2)      -> sent on as the next stage's zl
-// with all four matrices (and the past-tap matrix of layer 0) in registers; waves 4-7 (the
-// helpers) compute one phase ahead
-//     base_1 = Wc_1 xp + (Wc_1 Wr_prev) zl,    x_0 = xp + Wr_prev zl,  sk += Ws_prev zl + bs_prev
-//     base_2 = Wc_2 x_0 + (Wc_2 Wr_0) z_0,     x_1 = x_0 + Wr_0 z_0 + br_0,  sk += Ws_0 z_0 + bs_0
-//                                              x_2 = x_1 + Wr_1 z_1 + br_1,  sk += Ws_1 z_1 + bs_1
-// and send xp' = x_2 + br_2 and sk while the chain is still busy with z_2.  The constant
+//     z_1 = gate((Wc_1 Wr_0) z_0 + base_1 + pf_1)          and (Wc_2 Wr_0) z_0 for the helpers' base_2
+//     z_2 = gate((Wc_2 Wr_1) z_1 + base_2 + pf_2)          -> sent on as the next stage's zl
+// with their five matrices in registers; waves 4-7 (the helpers) compute one phase ahead
+//     base_1 = Wc_1 xp + (Wc_1 Wr_prev) zl,    x_0 = xp + Wr_prev zl
+//     base_2 = Wc_2 x_0  [+ the chain's term],  x_1 = x_0 + Wr_0 z_0 + br_0
+//                                               x_2 = x_1 + Wr_1 z_1 + br_1   -> xp' = x_2 + br_2 sent early
+// and, after the third phase, sk' = sk + Ws_prev zl + Ws_0 z_0 + Ws_1 z_1 + biases (the skip 1x1
+// of a stage's LAST layer is added by the next stage, the head for the last one).  The constant
 // vectors Wc_1 br_0 and Wc_2 (br_0 + br_1) are packed once and ride in pf_1 / pf_2.  The
-// explicit x_0, x_1, x_2 feed the dilation queues off the critical path, exactly as before.
+// explicit x_0, x_1, x_2 feed the dilation queues off the critical path, exactly as in PIPE.
 //
 // The products Wc Wr are formed once at pack time (fp64 sums, rounded to fp32).  The folded
 // form is the same real-number function as the reference's; its fp32 rounding differs from
@@ -42,14 +43,14 @@ namespace mvn {
 namespace fold {
 constexpr int C = 64, Q = 256, NT = 512, LPS = 3;
 constexpr int KQ = 4, KPER = 16, NF4 = 4;  // thread 4c + kq owns rows (c, C + c) x 16 inputs
-constexpr int MAT_F = 2 * C * C;           // one 2C x C matrix in the per-thread order
-// matrices of a stage section, in order
-enum { M_A0 = 0, M_A0P, M_A1, M_A2, M_WP0,      // chain waves: registers
-       M_B1, M_B1P, M_PP, M_B2, M_B2P,          // helper waves: registers
-       M_WP1, M_WP2, M_RS0, M_RS1,              // LDS
+constexpr int MAT_F = 2 * C * C;           // one 2C x C matrix (or two C x C ones) in the per-thread order
+// a stage section: 14 matrices, then the vectors
+enum { M_A0 = 0, M_A0P, M_A1, M_A2, M_B2P,       // chain waves: registers
+       M_B1, M_B1P, M_B2, M_RR, M_RS,            // helper waves: registers; RR = {Wr_prev; Wr_0}, RS = {Wr_1; Ws_1}
+       M_WP0, M_WP1, M_WP2, M_SS,                // LDS: past taps of the three layers, SS = {Ws_prev; Ws_0}
        N_MAT };
-// vectors behind the matrices: cb1[2C] = Wc_1 br_0, cb2[2C] = Wc_2 (br_0 + br_1), then
-// bs_prev, br_0, bs_0, br_1, bs_1, br_2 [C each]
+constexpr int N_LDS_MAT = 4;
+// vectors: cb1[2C] = Wc_1 br_0, cb2[2C] = Wc_2 (br_0 + br_1), then bs_prev, br_0, bs_0, br_1, bs_1, br_2 [C each]
 constexpr int V_CB1 = 0, V_CB2 = 2 * C, V_BSP = 4 * C, V_BR0 = 5 * C, V_BS0 = 6 * C, V_BR1 = 7 * C,
               V_BS1 = 8 * C, V_BR2 = 9 * C, VEC_F = 10 * C;
 constexpr int STAGE_F = N_MAT * MAT_F + VEC_F;
@@ -58,8 +59,8 @@ constexpr int EMB_F = 2 * Q * C;
 constexpr int W1_F = Q * C, W2_F = Q * Q, WSL_F = C * C;
 constexpr int HEAD_F = W1_F + Q + W2_F + Q + WSL_F + C;
 constexpr int GRAN = 3 * C;                 // granules per inbox: xp | zl | sk
-// LDS floats: layer stage 4 matrices + vectors; head stage the embedding tables + vectors
-constexpr int LDS_FLOATS = 4 * MAT_F + 1536 + 16;
+// LDS floats: layer stage matrices + vectors; head stage the embedding tables (32768) + vectors
+constexpr int LDS_FLOATS = N_LDS_MAT * MAT_F + 1536 + 16;
 }  // namespace fold
 
 struct FoldMat {
@@ -90,29 +91,68 @@ __device__ __forceinline__ void fold_dot_lds(const float *mat, int t, const floa
   rb = dot_stream<fold::NF4>((const f4 *)mat + fold::NF4 * 256, 256, t, xq);
 }
 
-// Wave 0: the 192-granule inbox.  Lane i takes granules 2i, 2i+1 (xp for i < 32, zl above) and
-// 128 + 2(i & 31), +1 (sk); each granule validated by its own epoch.
-__device__ __forceinline__ bool wait_inbox3(const u64 *in, unsigned epoch, unsigned *err, float (&v)[4]) {
-  const int lane = threadIdx.x & 63;
-  const u64 *p0 = in + 2 * lane, *p1 = in + 128 + 2 * (lane & 31);
-  for (unsigned spins = 1;; ++spins) {
-    v4u g0, g1;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                 "global_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(g0), "=&v"(g1) : "v"(p0), "v"(p1) : "memory");
-    const bool ok = g0.y == epoch && g0.w == epoch && g1.y == epoch && g1.w == epoch;
-    if (__all(ok)) {
-      v[0] = __uint_as_float(g0.x);
-      v[1] = __uint_as_float(g0.z);
-      v[2] = __uint_as_float(g1.x);
-      v[3] = __uint_as_float(g1.z);
-      return true;
+// LDS accesses by byte address: base register + immediate (an address formed from the dynamic
+// LDS symbol is a register per address; 20 of them spilled the chain's weights)
+typedef __attribute__((address_space(3))) float lds_f;
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) vf4 lds_f4;
+__device__ __forceinline__ f4 lds_load4(unsigned addr) {
+  const vf4 v = *(const lds_f4 *)(uintptr_t)addr;
+  f4 r;
+  r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)(uintptr_t)(lds_f *)p; }
+#define LDSF(addr, off) (*(lds_f *)(uintptr_t)((addr) + 4u * (unsigned)(off)))
+template <int N4>
+__device__ __forceinline__ void ldsv(f4 (&x)[N4], unsigned addr, int off) {
+#pragma unroll
+  for (int i = 0; i < N4; ++i) x[i] = lds_load4(addr + 4u * (unsigned)off + 16u * i);
+}
+
+// dot_stream() by byte addresses: N4 float4 of weights at waddr + 4096 i against the vector at xaddr
+template <int N4>
+__device__ __forceinline__ float dot_stream_a(unsigned waddr, unsigned xaddr) {
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll
+  for (int i0 = 0; i0 < N4; i0 += 4) {
+    f4 w[4], x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = lds_load4(waddr + 4096u * (i0 + i));
+      x[i] = lds_load4(xaddr + 16u * (i0 + i));
     }
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      a0 = __builtin_elementwise_fma(v2f{w[i].x, w[i].y}, v2f{x[i].x, x[i].y}, a0);
+      a1 = __builtin_elementwise_fma(v2f{w[i].z, w[i].w}, v2f{x[i].z, x[i].w}, a1);
+      a2 = __builtin_elementwise_fma(v2f{w[i + 1].x, w[i + 1].y}, v2f{x[i + 1].x, x[i + 1].y}, a2);
+      a3 = __builtin_elementwise_fma(v2f{w[i + 1].z, w[i + 1].w}, v2f{x[i + 1].z, x[i + 1].w}, a3);
+    }
+  }
+  const v2f t = (a0 + a2) + (a1 + a3);
+  return t.x + t.y;
+}
+
+// One granule of the skip lane, polled by the lane that owns the channel (off the chain: it was
+// sent a whole stage time ago).  A time-out raises the status word; the caller carries on with
+// the stale value (the host sees the word).
+__device__ __forceinline__ float wait_granule(const u64 *p, unsigned epoch, unsigned *err) {
+  for (unsigned spins = 1;; ++spins) {
+    unsigned lo, hi;
+    {
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      v2u g;
+      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+      lo = g.x;
+      hi = g.y;
+    }
+    if (hi == epoch) return __uint_as_float(lo);
     if ((spins & 255u) == 0) {
       const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e != 0 || spins > PIPE_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __uint_as_float(lo);
       }
     }
     __builtin_amdgcn_s_sleep(1);
@@ -158,23 +198,28 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
     const bool chain = tid < 256;
     const int t = tid & 255, c = t >> 2, kq = t & 3;
     const bool lead = kq == 0;
-    float *lmat = smem;                  // WP1 | WP2 | RS0 | RS1
-    float *vec = smem + 4 * MAT_F;
-    float *xpb = vec;                    // [C] inbox: stream without the last residual term
-    float *zlb = xpb + C;                // [C] inbox: previous stage's last gated activation
-    float *skb = zlb + C;                // [C] inbox: running skip sum
-    float *z0b = skb + C;                // [C]
-    float *z1b = z0b + C;                // [C]
-    float *x0b = z1b + C;                // [C] layer 0's input, explicit
-    float *base1 = x0b + C;              // [2C] helper -> chain
-    float *base2 = base1 + 2 * C;        // [2C]
-    float *pastb = base2 + 2 * C;        // [LPS][C] popped queue entries
-    float *ctxb = pastb + LPS * C;       // [C] context vector of the step being prepared
+    float *lmat = smem;                  // WP0 | WP1 | WP2 | SS
+    // LDS vectors, addressed as constant offsets from two per-lane bases (kept opaque so that
+    // every access is base register + immediate instead of a register per address)
+    constexpr int O_XP = 0;              // [C] inbox: stream without the last residual term
+    constexpr int O_ZL = C;              // [C] inbox: previous stage's last gated activation
+    constexpr int O_Z0 = 2 * C, O_Z1 = 3 * C;
+    constexpr int O_X0 = 4 * C;          // [C] layer 0's input, explicit
+    constexpr int O_B1 = 5 * C, O_B2 = 7 * C;  // [2C] each, helper -> chain
+    constexpr int O_PAST = 9 * C;        // [LPS][C] popped queue entries
+    constexpr int O_CTX = 12 * C;        // [C] context vector of the step being prepared
+    constexpr int O_VEC = 13 * C;        // [VEC_F] the stage's constant vectors
+    float *vec = smem + N_LDS_MAT * MAT_F;
+    unsigned vc = lds_addr(vec) + 4u * c;          // this lane's channel
+    unsigned vq = lds_addr(vec) + 4u * KPER * kq;  // this lane's 16 inputs
+    asm volatile("" : "+v"(vc), "+v"(vq));
+    u64 *ob = outbox + c;                // granules of this lane's channel: xp' | zl' (+ C) | sk' (+ 2C)
+    const u64 *ibs = inbox + 2 * C + c;
     float *ring = a.state + (size_t)b * a.state_per_seq;
     const float *sec = a.w + EMB_F + (size_t)s * STAGE_F;
     const float *vecs = sec + N_MAT * MAT_F;
 
-    // chain waves: A0, A0', A1, A2, WP0; helper waves: B1, B1', PP, B2, B2'
+    // chain waves: A0, A0', A1, A2, B2'; helper waves: B1, B1', B2, RR, RS
     FoldMat m0, m1, m2, m3, m4;
     {
       const int first = chain ? M_A0 : M_B1;
@@ -183,22 +228,18 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       fold_load(m2, sec + (size_t)(first + 2) * MAT_F, t);
       fold_load(m3, sec + (size_t)(first + 3) * MAT_F, t);
       fold_load(m4, sec + (size_t)(first + 4) * MAT_F, t);
-      const f4 *src = (const f4 *)(sec + (size_t)M_WP1 * MAT_F);
-      for (int i = tid; i < 4 * MAT_F / 4; i += NT) ((f4 *)lmat)[i] = src[i];
+      const f4 *src = (const f4 *)(sec + (size_t)M_WP0 * MAT_F);
+      for (int i = tid; i < N_LDS_MAT * MAT_F / 4; i += NT) ((f4 *)lmat)[i] = src[i];
     }
-    // chain lanes: past-tap sums (with the folded bias constants) of the three layers;
-    // helper lead lanes: biases, the explicit layer inputs of this step (queue pushes)
     // (the two groups never need each other's per-lane values: one set of registers serves
     // both -- chain: pf/pg of the three layers and the four folded-bias constants; helpers:
-    // xs of the three layers and the six biases)
+    // the explicit inputs xs of the three layers (queue pushes) and the six biases)
     float pf[LPS], pg[LPS];
     float (&xs)[LPS] = pf;
     int doff[LPS], dmask[LPS];
-    const float kc0 = vecs[chain ? V_CB1 + c : V_BSP + c], kc1 = vecs[chain ? V_CB1 + C + c : V_BR0 + c];
-    const float kc2 = vecs[chain ? V_CB2 + c : V_BS0 + c], kc3 = vecs[chain ? V_CB2 + C + c : V_BR1 + c];
-    const float kc4 = vecs[V_BS1 + c], kc5 = vecs[V_BR2 + c];
-    const float cb1f = kc0, cb1g = kc1, cb2f = kc2, cb2g = kc3;               // chain
-    const float bsp = kc0, br0 = kc1, bs0 = kc2, br1 = kc3, bs1 = kc4, br2 = kc5;  // helpers
+    // the stage's bias vectors live in LDS behind the step vectors (read where needed: the six
+    // per-lane copies cost the chain its registers)
+    for (int i = tid; i < VEC_F; i += NT) vec[O_VEC + i] = vecs[i];
 #pragma unroll
     for (int j = 0; j < LPS; ++j) {
       pf[j] = 0.f; pg[j] = 0.f;
@@ -209,8 +250,8 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
 
     // Off the critical path: push this step's layer inputs into the dilation queues, pop the
     // entries step tn needs (helper lead lanes), then the past-tap half of step tn's f/g sums
-    // (chain waves).  Addresses are rebuilt here behind an optimisation fence (the chain needs
-    // the registers, this code has slack).
+    // (chain waves, matrices streamed from LDS).  Addresses are rebuilt here behind an
+    // optimisation fence (the chain needs the registers, this code has slack).
     auto precompute = [&](int tn, bool push) {
       int tq = t;
       asm volatile("" : "+v"(tq));
@@ -222,30 +263,30 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
             float *base = ring + doff[j] + cq;
             if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
             const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
-            pastb[j * C + cq] = pv;
+            vec[O_PAST + j * C + cq] = pv;
           }
       }
-      if (a.ctx_tm && chain && tq < C) ctxb[tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
+      if (a.ctx_tm && chain && tq < C) vec[O_CTX + tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
       if (chain) {
         float f0, g0, f1, g1, f2, g2;
-        fold_dot(m4, pastb + KPER * kk, f0, g0);  // WP0 lives in this group's registers
-        fold_dot_lds(lmat, tq, pastb + C + KPER * kk, f1, g1);
-        fold_dot_lds(lmat + MAT_F, tq, pastb + 2 * C + KPER * kk, f2, g2);
+        fold_dot_lds(lmat, tq, vec + O_PAST + KPER * kk, f0, g0);
+        fold_dot_lds(lmat + MAT_F, tq, vec + O_PAST + C + KPER * kk, f1, g1);
+        fold_dot_lds(lmat + 2 * MAT_F, tq, vec + O_PAST + 2 * C + KPER * kk, f2, g2);
         pf[0] = chan_sum<KQ>(f0);
         pg[0] = chan_sum<KQ>(g0);
-        pf[1] = chan_sum<KQ>(f1) + cb1f;
-        pg[1] = chan_sum<KQ>(g1) + cb1g;
-        pf[2] = chan_sum<KQ>(f2) + cb2f;
-        pg[2] = chan_sum<KQ>(g2) + cb2g;
+        pf[1] = chan_sum<KQ>(f1) + vec[O_VEC + V_CB1 + cq];
+        pg[1] = chan_sum<KQ>(g1) + vec[O_VEC + V_CB1 + C + cq];
+        pf[2] = chan_sum<KQ>(f2) + vec[O_VEC + V_CB2 + cq];
+        pg[2] = chan_sum<KQ>(g2) + vec[O_VEC + V_CB2 + C + cq];
         if (a.ctx_tm) {
           // 1x1 context convs (modules.py:58-63, :75-77), weights streamed from L2
 #pragma unroll
           for (int j = 0; j < LPS; ++j)
             if (j < nl) {
               const float *wc = a.wctx + (size_t)(l0 + j) * CTX_LAYER_F;
-              pf[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc, 256, tq, ctxb + KPER * kk)) + wc[MAT_F + cq];
-              pg[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc + NF4 * 256, 256, tq, ctxb + KPER * kk)) +
+              pf[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc, 256, tq, vec + O_CTX + KPER * kk)) + wc[MAT_F + cq];
+              pg[j] += chan_sum<KQ>(dot_stream<NF4>((const f4 *)wc + NF4 * 256, 256, tq, vec + O_CTX + KPER * kk)) +
                        wc[MAT_F + C + cq];
             }
         }
@@ -257,121 +298,120 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
     for (int ts = a.t_begin; ts < a.t_end; ++ts) {
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       if (wave == 0) {
-        float v[4];
-        const bool ok = wait_inbox3(inbox, epoch, err, v);
+        // 2C granules: lane i takes 2i, 2i + 1 (xp for i < 32, zl above) with one 16-byte load
+        float v[2];
+        const bool ok = wait_inbox<2>(inbox, epoch, err, v);
         if (ok) {
-          float *dst = lane < 32 ? xpb + 2 * lane : zlb + 2 * (lane - 32);
+          float *dst = vec + 2 * lane;  // O_XP and O_ZL are adjacent
           dst[0] = v[0];
           dst[1] = v[1];
-          if (lane < 32) {
-            skb[2 * lane] = v[2];
-            skb[2 * lane + 1] = v[3];
-          }
         }
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
-      float skacc = 0.f, xv = 0.f;  // helper lead lanes: running skip sum, explicit stream
+      float xv = 0.f;  // helper lead lanes: the explicit stream
       MVN_FINE(b, s, ts - a.t_begin, 0, 0);
       // ---- phase 0
       if (chain) {
-        float f, g, f2, g2;
-        fold_dot(m0, xpb + KPER * kq, f, g);
-        fold_dot(m1, zlb + KPER * kq, f2, g2);
-        f = chan_sum<KQ>(f + f2) + pf[0];
-        g = chan_sum<KQ>(g + g2) + pg[0];
+        f4 xa[NF4], xb[NF4];
+        ldsv<NF4>(xa, vq, O_XP);
+        ldsv<NF4>(xb, vq, O_ZL);
+        float f = dotn<NF4>(m0.a, xa) + dotn<NF4>(m1.a, xb);
+        float g = dotn<NF4>(m0.b, xa) + dotn<NF4>(m1.b, xb);
+        f = chan_sum<KQ>(f) + pf[0];
+        g = chan_sum<KQ>(g) + pg[0];
         const float z = gate_fast(f, g);
-        if (lead) z0b[c] = z;
+        if (lead) LDSF(vc, O_Z0) = z;
         MVN_FINE(b, s, ts - a.t_begin, 1, 0);
       } else {
-        float f, g, f2, g2, r, k;
-        fold_dot(m0, xpb + KPER * kq, f, g);
-        fold_dot(m1, zlb + KPER * kq, f2, g2);
-#if MVN_EXP == 3 || MVN_EXP == 4
-        r = 0.f; k = 0.f;
-#else
-        fold_dot(m2, zlb + KPER * kq, r, k);
-#endif
-        f = chan_sum<KQ>(f + f2);
-        g = chan_sum<KQ>(g + g2);
+        f4 xa[NF4], xb[NF4];
+        ldsv<NF4>(xa, vq, O_XP);
+        ldsv<NF4>(xb, vq, O_ZL);
+        float r = dotn<NF4>(m3.a, xb);                             // Wr_prev zl
+        float f = dotn<NF4>(m0.a, xa) + dotn<NF4>(m1.a, xb);
+        float g = dotn<NF4>(m0.b, xa) + dotn<NF4>(m1.b, xb);
         r = chan_sum<KQ>(r);
-        k = chan_sum<KQ>(k);
+        f = chan_sum<KQ>(f);
+        g = chan_sum<KQ>(g);
         if (lead) {
-          base1[c] = f;
-          base1[C + c] = g;
-          xv = xpb[c] + r;               // x_0 (br_prev already inside xp)
-          skacc = skb[c] + (k + bsp);
-          x0b[c] = xv;
+          xv = LDSF(vc, O_XP) + r;               // x_0 (br_prev already inside xp)
+          LDSF(vc, O_X0) = xv;
           xs[0] = xv;
+          LDSF(vc, O_B1) = f;
+          LDSF(vc, O_B1 + C) = g;
         }
         MVN_FINE(b, s, ts - a.t_begin, 6, 256);
       }
       lds_barrier();
       MVN_FINE(b, s, ts - a.t_begin, 2, 0);
       // ---- phase 1
+      float b2f = 0.f, b2g = 0.f;  // chain: (Wc_2 Wr_0) z_0, this thread's 16 inputs
       if (chain) {
-        float f, g;
-        fold_dot(m2, z0b + KPER * kq, f, g);
-        f = chan_sum<KQ>(f) + (base1[c] + pf[1]);
-        g = chan_sum<KQ>(g) + (base1[C + c] + pg[1]);
+        f4 xz[NF4];
+        ldsv<NF4>(xz, vq, O_Z0);
+        float f = dotn<NF4>(m2.a, xz), g = dotn<NF4>(m2.b, xz);
+        f = chan_sum<KQ>(f) + (LDSF(vc, O_B1) + pf[1]);
+        g = chan_sum<KQ>(g) + (LDSF(vc, O_B1 + C) + pg[1]);
         const float z = gate_fast(f, g);
-        if (lead) z1b[c] = z;
+        if (lead) LDSF(vc, O_Z1) = z;
+        b2f = dotn<NF4>(m4.a, xz);
+        b2g = dotn<NF4>(m4.b, xz);
         MVN_FINE(b, s, ts - a.t_begin, 3, 0);
       } else {
-        float f, g, f2, g2, r, k;
-#if MVN_EXP == 4
-        f = g = f2 = g2 = 0.f;
-#else
-        fold_dot(m3, x0b + KPER * kq, f, g);
-        fold_dot(m4, z0b + KPER * kq, f2, g2);
-#endif
-        f = chan_sum<KQ>(f + f2);
-        g = chan_sum<KQ>(g + g2);
-        if (lead) {
-          base2[c] = f;
-          base2[C + c] = g;
-        }
-#if MVN_EXP == 3 || MVN_EXP == 4
-        r = 0.f; k = 0.f;
-#else
-        fold_dot_lds(lmat + 2 * MAT_F, t, z0b + KPER * kq, r, k);  // RS0
-#endif
+        f4 xa[NF4], xz[NF4];
+        ldsv<NF4>(xa, vq, O_X0);
+        ldsv<NF4>(xz, vq, O_Z0);
+        const float br0 = LDSF(vc, O_VEC + V_BR0);
+        float f = dotn<NF4>(m2.a, xa), g = dotn<NF4>(m2.b, xa);    // Wc_2 x_0
+        float r = dotn<NF4>(m3.b, xz);                             // Wr_0 z_0
+        f = chan_sum<KQ>(f);
+        g = chan_sum<KQ>(g);
         r = chan_sum<KQ>(r);
-        k = chan_sum<KQ>(k);
         if (lead) {
+          LDSF(vc, O_B2) = f;
+          LDSF(vc, O_B2 + C) = g;
           xv = (xv + br0) + r;           // x_1
-          skacc += k + bs0;
           xs[1] = xv;
         }
         MVN_FINE(b, s, ts - a.t_begin, 7, 256);
       }
       lds_barrier();
       MVN_FINE(b, s, ts - a.t_begin, 4, 0);
-      // ---- phase 2: the chain's z_2 and the helpers' {xp', sk} leave as granules
+      // ---- phase 2: the chain's z_2 and the helpers' xp' leave as granules; the skip sum follows
       if (chain) {
-        float f, g;
-        fold_dot(m3, z1b + KPER * kq, f, g);
-        f = chan_sum<KQ>(f) + (base2[c] + pf[2]);
-        g = chan_sum<KQ>(g) + (base2[C + c] + pg[2]);
+        f4 xz[NF4];
+        ldsv<NF4>(xz, vq, O_Z1);
+        float f = dotn<NF4>(m3.a, xz) + b2f, g = dotn<NF4>(m3.b, xz) + b2g;
+        f = chan_sum<KQ>(f) + (LDSF(vc, O_B2) + pf[2]);
+        g = chan_sum<KQ>(g) + (LDSF(vc, O_B2 + C) + pg[2]);
         const float z = gate_fast(f, g);
-        if (lead) put_granule(outbox + C + c, epoch, z, fast_edge);
+        if (lead) put_granule(ob + C, epoch, z, fast_edge);
         MVN_FINE(b, s, ts - a.t_begin, 5, 0);
       } else {
-        float r, k;
-#if MVN_EXP == 3 || MVN_EXP == 4
-        r = 0.f; k = 0.f;
-#else
-        fold_dot_lds(lmat + 3 * MAT_F, t, z1b + KPER * kq, r, k);  // RS1
-#endif
+        f4 xz[NF4];
+        ldsv<NF4>(xz, vq, O_Z1);
+        const float br12 = LDSF(vc, O_VEC + V_BR1), br2 = LDSF(vc, O_VEC + V_BR2);
+        float r = dotn<NF4>(m4.a, xz);                             // Wr_1 z_1
         r = chan_sum<KQ>(r);
-        k = chan_sum<KQ>(k);
         if (lead) {
-          xv = (xv + br1) + r;           // x_2
-          skacc += k + bs1;
+          xv = (xv + br12) + r;          // x_2
           xs[2] = xv;
-          put_granule(outbox + c, epoch, xv + br2, fast_edge);
-          put_granule(outbox + 2 * C + c, epoch, skacc, fast_edge);
+          put_granule(ob, epoch, xv + br2, fast_edge);
+        }
+        // skip lane: sk' = sk + (Ws_prev zl + bs_prev) + (Ws_0 z_0 + bs_0) + (Ws_1 z_1 + bs_1)
+        float k1 = dotn<NF4>(m4.b, xz);
+        unsigned wss = lds_addr(lmat + 3 * MAT_F) + 16u * t;  // SS = {Ws_prev; Ws_0}
+        asm volatile("" : "+v"(wss));
+        float kp = dot_stream_a<NF4>(wss, vq + 4u * O_ZL);
+        float k0 = dot_stream_a<NF4>(wss + 4096u * NF4, vq + 4u * O_Z0);
+        kp = chan_sum<KQ>(kp);
+        k0 = chan_sum<KQ>(k0);
+        k1 = chan_sum<KQ>(k1);
+        if (lead) {
+          const float bsp = LDSF(vc, O_VEC + V_BSP), bs0 = LDSF(vc, O_VEC + V_BS0), bs1 = LDSF(vc, O_VEC + V_BS1);
+          const float skin = wait_granule(ibs, epoch, err);
+          put_granule(ob + 2 * C, epoch, ((skin + (kp + bsp)) + (k0 + bs0)) + (k1 + bs1), fast_edge);
         }
       }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
@@ -381,9 +421,11 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
         precompute(ts + 1, true);
       } else if (!chain && lead) {
         // last step of the launch: push only (the next launch pops in its prologue)
+        int cq = c;
+        asm volatile("" : "+v"(cq));
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
-          if (j < nl) ring[doff[j] + c + (ts & dmask[j]) * C] = xs[j];
+          if (j < nl) ring[doff[j] + cq + (ts & dmask[j]) * C] = xs[j];
       }
     }
     return;
@@ -392,10 +434,9 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
   // ============================ head stage ============================
   {
     float *tab = smem;                    // embedding tables [2][Q][C] (128 KB)
-    float *vec = smem + 4 * MAT_F;
+    float *vec = smem + N_LDS_MAT * MAT_F;
     float *zlb = vec;                     // [C] last layer's gated activation
-    float *skb = zlb + C;                 // [C] skip sum without the last layer
-    float *a0 = skb + C;                  // [C] lrelu(skip)
+    float *a0 = zlb + C;                  // [C] lrelu(skip)
     float *a1 = a0 + C;                   // [Q]
     float *lgb = a1 + Q;                  // [Q] logits
     const float *E0 = tab, *E1 = tab + Q * C;
@@ -449,32 +490,32 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       int next_idx = 0;
       if (wave == 0) {
         if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
-        float v[4];
-        const bool ok = wait_inbox3(inbox, epoch, err, v);
-        if (ok) {
-          if (lane >= 32) {
-            zlb[2 * (lane - 32)] = v[0];
-            zlb[2 * (lane - 32) + 1] = v[1];
-          } else {
-            skb[2 * lane] = v[2];
-            skb[2 * lane + 1] = v[3];
-          }
+        float v[2];
+        const bool ok = wait_inbox64(inbox + C, epoch, err, v);  // zl (the last stage's xp' is not used)
+        if (ok && lane < 32) {
+          zlb[2 * lane] = v[0];
+          zlb[2 * lane + 1] = v[1];
         }
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
+      float sv = 0.f;
       if (do_head) {
-        {
-          // skip sum + the last layer's skip 1x1 (modules.py:90-91), then the head's first
-          // leaky-ReLU (modules.py:140)
-          f4 x[2];
-          ldsn<2>(x, zlb + 8 * q2);
-          float sv = dotn<2>(wsl, x);
-          sv = quad_sum(sv);
-          sv += other_quad(sv);
-          if (q2 == 0) a0[og] = leaky(skb[og] + (sv + bslr));
-        }
+        // the last layer's skip 1x1 (modules.py:90-91)
+        f4 x[2];
+        ldsn<2>(x, zlb + 8 * q2);
+        sv = dotn<2>(wsl, x);
+        sv = quad_sum(sv);
+        sv += other_quad(sv);
+      }
+      // the skip lane ends here, every step (the step's skip sums have then been consumed all
+      // along the pipeline before the next sample enters it)
+      float skin = 0.f;
+      if (q2 == 0) skin = wait_granule(inbox + 2 * C + og, epoch, err);
+      if (do_head) {
+        // skip sum, then the head's first leaky-ReLU (modules.py:140)
+        if (q2 == 0) a0[og] = leaky(skin + (sv + bslr));
         lds_barrier();
         {
           f4 x[8];
@@ -573,26 +614,23 @@ __global__ void pack_fold_stage_kernel(FoldLayers p, float *__restrict__ dst) {
     for (int m = 0; m < C; ++m) acc += fold_wc(p, jc, row, m) * fold_wr(p, jr, m, k);
     return acc;
   };
-  auto rs = [&](int j) {  // rows [0,C) residual, [C,2C) skip of layer j
-    if (row < C) return fold_wr(p, j, row, k);
-    return p.sw[j] ? (double)p.sw[j][(size_t)(row - C) * C + k] : 0.0;
-  };
+  auto ws = [&](int j, int o) { return p.sw[j] ? (double)p.sw[j][(size_t)o * C + k] : 0.0; };
   auto wp = [&](int j) { return p.fw[j] ? (double)fg_elem(p.fw[j], p.gw[j], C, row, k) : 0.0; };  // past tap
   switch (mat) {
     case M_A0: v = fold_wc(p, 1, row, k); break;
     case M_A0P: v = prod(1, 0); break;
     case M_A1: v = prod(2, 1); break;
     case M_A2: v = prod(3, 2); break;
-    case M_WP0: v = wp(1); break;
+    case M_B2P: v = prod(3, 1); break;
     case M_B1: v = fold_wc(p, 2, row, k); break;
     case M_B1P: v = prod(2, 0); break;
-    case M_PP: v = rs(0); break;
     case M_B2: v = fold_wc(p, 3, row, k); break;
-    case M_B2P: v = prod(3, 1); break;
+    case M_RR: v = row < C ? fold_wr(p, 0, row, k) : fold_wr(p, 1, row - C, k); break;
+    case M_RS: v = row < C ? fold_wr(p, 2, row, k) : ws(2, row - C); break;
+    case M_WP0: v = wp(1); break;
     case M_WP1: v = wp(2); break;
     case M_WP2: v = wp(3); break;
-    case M_RS0: v = rs(1); break;
-    case M_RS1: v = rs(2); break;
+    case M_SS: v = row < C ? ws(0, row) : ws(1, row - C); break;
   }
   dst[i] = (float)v;
 }
@@ -617,9 +655,9 @@ __global__ void pack_fold_head_kernel(const float *w1, const float *b1, const fl
     // last layer's skip 1x1: [2][tid (512)] float4, thread (cs = tid >> 3, q8 = tid & 7) owns 8 inputs
     const int ii = i - (W1_F + Q + W2_F + Q);
     const int e = ii & 3, v = ii >> 2, tid = v & (NT - 1), i2 = v >> 9;
-    dst[i] = sw_last[(size_t)(tid >> 3) * C + 8 * (tid & 7) + 4 * i2 + e];
+    dst[i] = sw_last ? sw_last[(size_t)(tid >> 3) * C + 8 * (tid & 7) + 4 * i2 + e] : 0.f;
   } else if (i < HEAD_F) {
-    dst[i] = sb_last[i - (W1_F + Q + W2_F + Q + WSL_F)];
+    dst[i] = sb_last ? sb_last[i - (W1_F + Q + W2_F + Q + WSL_F)] : 0.f;
   }
 }
 
@@ -664,18 +702,14 @@ int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t
     hipLaunchKernelGGL(pack_fold_stage_kernel, dim3((STAGE_F + 255) / 256), dim3(256), 0, s, fl,
                        packed + EMB_F + (size_t)st * STAGE_F);
   }
-  // the head adds the skip 1x1 of the last layer of the last stage (index NSL * LPS - 1 when
-  // L is a multiple of LPS; otherwise that slot is a zero layer and the real last layer's skip
-  // was already added inside its stage)
+  // the head adds the skip 1x1 of the last stage's THIRD layer (index NSL * LPS - 1); when the
+  // model ends earlier that slot is a zero layer (packed as zeros here) and the real last
+  // layer's skip term was already added inside its stage
   const int l_tail = NSL * LPS - 1;
   const bool tail_real = l_tail < L;
-  float *zeros = nullptr;  // a zero layer: Ws = 0, bs = 0 -- take them from the packed stage's
-                           // own zero vectors (V_BR2 of a stage whose layer 2 does not exist)
-  if (!tail_real) zeros = packed + EMB_F + (size_t)(NSL - 1) * STAGE_F + (size_t)M_RS1 * MAT_F;
-  // (M_RS1 of the last stage is all zero when its layer 2 does not exist: C*C + C zeros follow)
   hipLaunchKernelGGL(pack_fold_head_kernel, dim3((HEAD_F + 255) / 256), dim3(256), 0, s, p->head1_w, p->head1_b,
-                     p->head2_w, p->head2_b, tail_real ? p->skip_w[l_tail] : zeros,
-                     tail_real ? p->skip_b[l_tail] : zeros, packed + EMB_F + (size_t)NSL * STAGE_F);
+                     p->head2_w, p->head2_b, tail_real ? p->skip_w[l_tail] : nullptr,
+                     tail_real ? p->skip_b[l_tail] : nullptr, packed + EMB_F + (size_t)NSL * STAGE_F);
   return check_hip(hipGetLastError(), "fold_pack");
 }
 
