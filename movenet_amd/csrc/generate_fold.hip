@@ -63,32 +63,65 @@ constexpr int GRAN = 3 * C;                 // granules per inbox: xp | zl | sk
 constexpr int LDS_FLOATS = N_LDS_MAT * MAT_F + 1536 + 16;
 }  // namespace fold
 
+// A thread's share of a matrix: 32 floats = 8 float4 of the packed order.  Two formats:
+//  * PAIR (the 2C x C matrices): w[k] = {row c, row C + c} at input k of the thread's 16: one
+//    packed FMA against {x_k, x_k} (an op_sel broadcast) advances BOTH rows, the four
+//    accumulators end as {f, g} -- 16 FMAs + 3 packed adds for the two rows, where separate
+//    rows cost 16 + 6 + 2 (the kernel is bound by VALU issue: scripts/probes/issue_rates.hip)
+//  * SPLIT (two unrelated C x C matrices): a() = w[0..8) is row c of the first against
+//    inputs {2i, 2i + 1}, b() = w[8..16) the same row of the second
 struct FoldMat {
-  v2f a[2 * fold::NF4], b[2 * fold::NF4];  // rows c and C + c, 16 inputs each
+  v2f w[16];
 };
 __device__ __forceinline__ void fold_load(FoldMat &m, const float *sec, int t) {
-  loadn<fold::NF4>(m.a, (const f4 *)sec, 256, t);
-  loadn<fold::NF4>(m.b, (const f4 *)sec + fold::NF4 * 256, 256, t);
-}
-__device__ __forceinline__ void fold_zero(FoldMat &m) {
 #pragma unroll
-  for (int i = 0; i < 2 * fold::NF4; ++i) {
-    m.a[i] = v2f{0.f, 0.f};
-    m.b[i] = v2f{0.f, 0.f};
+  for (int i = 0; i < 8; ++i) {
+    const f4 v = ((const f4 *)sec)[i * 256 + t];
+    m.w[2 * i] = v2f{v.x, v.y};
+    m.w[2 * i + 1] = v2f{v.z, v.w};
   }
 }
-// both rows of a register-resident matrix against 16 inputs of an LDS vector (partial sums:
-// the four lanes of a channel are combined by the caller)
-__device__ __forceinline__ void fold_dot(const FoldMat &m, const float *xq, float &ra, float &rb) {
-  f4 x[fold::NF4];
-  ldsn<fold::NF4>(x, xq);
-  ra = dotn<fold::NF4>(m.a, x);
-  rb = dotn<fold::NF4>(m.b, x);
+// acc (+)= w * {x.y, x.y}: the compiler finds the op_sel form for the high element of a
+// register pair only every other time (it copies .w to a fresh register first), so it is spelled out
+__device__ __forceinline__ v2f pk_fma_hi(v2f w, v2f xpair, v2f acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(w), "v"(xpair));
+  return acc;
 }
-// the same with the matrix in LDS ([2 NF4][256] float4, per-thread order)
-__device__ __forceinline__ void fold_dot_lds(const float *mat, int t, const float *xq, float &ra, float &rb) {
-  ra = dot_stream<fold::NF4>((const f4 *)mat, 256, t, xq);
-  rb = dot_stream<fold::NF4>((const f4 *)mat + fold::NF4 * 256, 256, t, xq);
+__device__ __forceinline__ v2f pk_mul_hi(v2f w, v2f xpair) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(w), "v"(xpair));
+  return r;
+}
+// PAIR format: acc[j] (+)= w[4i + j] * {x[i][j], x[i][j]}
+template <bool INIT>
+__device__ __forceinline__ void pair_acc(v2f (&acc)[4], const v2f (&w)[16], const f4 (&x)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (INIT && i == 0) {
+      acc[0] = w[0] * v2f{x[0].x, x[0].x};
+      acc[1] = w[1] * v2f{x[0].y, x[0].y};
+      acc[2] = w[2] * v2f{x[0].z, x[0].z};
+      acc[3] = pk_mul_hi(w[3], v2f{x[0].z, x[0].w});
+    } else {
+      acc[0] = __builtin_elementwise_fma(w[4 * i], v2f{x[i].x, x[i].x}, acc[0]);
+      acc[1] = __builtin_elementwise_fma(w[4 * i + 1], v2f{x[i].y, x[i].y}, acc[1]);
+      acc[2] = __builtin_elementwise_fma(w[4 * i + 2], v2f{x[i].z, x[i].z}, acc[2]);
+      acc[3] = pk_fma_hi(w[4 * i + 3], v2f{x[i].z, x[i].w}, acc[3]);
+    }
+  }
+}
+__device__ __forceinline__ v2f pair_sum(const v2f (&acc)[4]) { return (acc[0] + acc[2]) + (acc[1] + acc[3]); }
+// SPLIT format, half H: one row against the 16 inputs
+template <int H>
+__device__ __forceinline__ float split_dot(const v2f (&w)[16], const f4 (&x)[4]) {
+  v2f a0 = w[8 * H] * v2f{x[0].x, x[0].y}, a1 = w[8 * H + 1] * v2f{x[0].z, x[0].w};
+  v2f a2 = w[8 * H + 2] * v2f{x[1].x, x[1].y}, a3 = w[8 * H + 3] * v2f{x[1].z, x[1].w};
+  a0 = __builtin_elementwise_fma(w[8 * H + 4], v2f{x[2].x, x[2].y}, a0);
+  a1 = __builtin_elementwise_fma(w[8 * H + 5], v2f{x[2].z, x[2].w}, a1);
+  a2 = __builtin_elementwise_fma(w[8 * H + 6], v2f{x[3].x, x[3].y}, a2);
+  a3 = __builtin_elementwise_fma(w[8 * H + 7], v2f{x[3].z, x[3].w}, a3);
+  const v2f t = (a0 + a2) + (a1 + a3);
+  return t.x + t.y;
 }
 
 // LDS accesses by byte address: base register + immediate (an address formed from the dynamic
@@ -110,26 +143,42 @@ __device__ __forceinline__ void ldsv(f4 (&x)[N4], unsigned addr, int off) {
   for (int i = 0; i < N4; ++i) x[i] = lds_load4(addr + 4u * (unsigned)off + 16u * i);
 }
 
-// dot_stream() by byte addresses: N4 float4 of weights at waddr + 4096 i against the vector at xaddr
-template <int N4>
-__device__ __forceinline__ float dot_stream_a(unsigned waddr, unsigned xaddr) {
-  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+// PAIR-format matrix streamed from LDS (eight float4 at waddr + 4096 i) against 16 inputs at xaddr
+__device__ __forceinline__ v2f pair_dot_lds(unsigned waddr, unsigned xaddr) {
+  v2f acc[4];
 #pragma unroll
-  for (int i0 = 0; i0 < N4; i0 += 4) {
-    f4 w[4], x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[i] = lds_load4(waddr + 4096u * (i0 + i));
-      x[i] = lds_load4(xaddr + 16u * (i0 + i));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-      a0 = __builtin_elementwise_fma(v2f{w[i].x, w[i].y}, v2f{x[i].x, x[i].y}, a0);
-      a1 = __builtin_elementwise_fma(v2f{w[i].z, w[i].w}, v2f{x[i].z, x[i].w}, a1);
-      a2 = __builtin_elementwise_fma(v2f{w[i + 1].x, w[i + 1].y}, v2f{x[i + 1].x, x[i + 1].y}, a2);
-      a3 = __builtin_elementwise_fma(v2f{w[i + 1].z, w[i + 1].w}, v2f{x[i + 1].z, x[i + 1].w}, a3);
+  for (int i = 0; i < 4; ++i) {
+    const f4 wa = lds_load4(waddr + 4096u * (2 * i)), wb = lds_load4(waddr + 4096u * (2 * i + 1));
+    const f4 x = lds_load4(xaddr + 16u * i);
+    if (i == 0) {
+      acc[0] = v2f{wa.x, wa.y} * v2f{x.x, x.x};
+      acc[1] = v2f{wa.z, wa.w} * v2f{x.y, x.y};
+      acc[2] = v2f{wb.x, wb.y} * v2f{x.z, x.z};
+      acc[3] = pk_mul_hi(v2f{wb.z, wb.w}, v2f{x.z, x.w});
+    } else {
+      acc[0] = __builtin_elementwise_fma(v2f{wa.x, wa.y}, v2f{x.x, x.x}, acc[0]);
+      acc[1] = __builtin_elementwise_fma(v2f{wa.z, wa.w}, v2f{x.y, x.y}, acc[1]);
+      acc[2] = __builtin_elementwise_fma(v2f{wb.x, wb.y}, v2f{x.z, x.z}, acc[2]);
+      acc[3] = pk_fma_hi(v2f{wb.z, wb.w}, v2f{x.z, x.w}, acc[3]);
     }
   }
+  return pair_sum(acc);
+}
+// SPLIT-format half H of a matrix streamed from LDS
+template <int H>
+__device__ __forceinline__ float split_dot_lds(unsigned waddr, unsigned xaddr) {
+  f4 w[4], x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i] = lds_load4(waddr + 4096u * (4 * H + i));
+    x[i] = lds_load4(xaddr + 16u * i);
+  }
+  v2f a0 = v2f{w[0].x, w[0].y} * v2f{x[0].x, x[0].y}, a1 = v2f{w[0].z, w[0].w} * v2f{x[0].z, x[0].w};
+  v2f a2 = v2f{w[1].x, w[1].y} * v2f{x[1].x, x[1].y}, a3 = v2f{w[1].z, w[1].w} * v2f{x[1].z, x[1].w};
+  a0 = __builtin_elementwise_fma(v2f{w[2].x, w[2].y}, v2f{x[2].x, x[2].y}, a0);
+  a1 = __builtin_elementwise_fma(v2f{w[2].z, w[2].w}, v2f{x[2].z, x[2].w}, a1);
+  a2 = __builtin_elementwise_fma(v2f{w[3].x, w[3].y}, v2f{x[3].x, x[3].y}, a2);
+  a3 = __builtin_elementwise_fma(v2f{w[3].z, w[3].w}, v2f{x[3].z, x[3].w}, a3);
   const v2f t = (a0 + a2) + (a1 + a3);
   return t.x + t.y;
 }
@@ -269,16 +318,16 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       if (a.ctx_tm && chain && tq < C) vec[O_CTX + tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
       if (chain) {
-        float f0, g0, f1, g1, f2, g2;
-        fold_dot_lds(lmat, tq, vec + O_PAST + KPER * kk, f0, g0);
-        fold_dot_lds(lmat + MAT_F, tq, vec + O_PAST + C + KPER * kk, f1, g1);
-        fold_dot_lds(lmat + 2 * MAT_F, tq, vec + O_PAST + 2 * C + KPER * kk, f2, g2);
-        pf[0] = chan_sum<KQ>(f0);
-        pg[0] = chan_sum<KQ>(g0);
-        pf[1] = chan_sum<KQ>(f1) + vec[O_VEC + V_CB1 + cq];
-        pg[1] = chan_sum<KQ>(g1) + vec[O_VEC + V_CB1 + C + cq];
-        pf[2] = chan_sum<KQ>(f2) + vec[O_VEC + V_CB2 + cq];
-        pg[2] = chan_sum<KQ>(g2) + vec[O_VEC + V_CB2 + C + cq];
+        const unsigned wm = lds_addr(lmat) + 16u * tq, xq = lds_addr(vec) + 4u * (O_PAST + KPER * kk);
+        const v2f p0 = pair_dot_lds(wm, xq);
+        const v2f p1 = pair_dot_lds(wm + 4u * MAT_F, xq + 4u * C);
+        const v2f p2 = pair_dot_lds(wm + 8u * MAT_F, xq + 8u * C);
+        pf[0] = chan_sum<KQ>(p0.x);
+        pg[0] = chan_sum<KQ>(p0.y);
+        pf[1] = chan_sum<KQ>(p1.x) + vec[O_VEC + V_CB1 + cq];
+        pg[1] = chan_sum<KQ>(p1.y) + vec[O_VEC + V_CB1 + C + cq];
+        pf[2] = chan_sum<KQ>(p2.x) + vec[O_VEC + V_CB2 + cq];
+        pg[2] = chan_sum<KQ>(p2.y) + vec[O_VEC + V_CB2 + C + cq];
         if (a.ctx_tm) {
           // 1x1 context convs (modules.py:58-63, :75-77), weights streamed from L2
 #pragma unroll
@@ -317,10 +366,12 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
         f4 xa[NF4], xb[NF4];
         ldsv<NF4>(xa, vq, O_XP);
         ldsv<NF4>(xb, vq, O_ZL);
-        float f = dotn<NF4>(m0.a, xa) + dotn<NF4>(m1.a, xb);
-        float g = dotn<NF4>(m0.b, xa) + dotn<NF4>(m1.b, xb);
-        f = chan_sum<KQ>(f) + pf[0];
-        g = chan_sum<KQ>(g) + pg[0];
+        v2f acc[4];
+        pair_acc<true>(acc, m0.w, xa);
+        pair_acc<false>(acc, m1.w, xb);
+        const v2f fg = pair_sum(acc);
+        const float f = chan_sum<KQ>(fg.x) + pf[0];
+        const float g = chan_sum<KQ>(fg.y) + pg[0];
         const float z = gate_fast(f, g);
         if (lead) LDSF(vc, O_Z0) = z;
         MVN_FINE(b, s, ts - a.t_begin, 1, 0);
@@ -328,12 +379,14 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
         f4 xa[NF4], xb[NF4];
         ldsv<NF4>(xa, vq, O_XP);
         ldsv<NF4>(xb, vq, O_ZL);
-        float r = dotn<NF4>(m3.a, xb);                             // Wr_prev zl
-        float f = dotn<NF4>(m0.a, xa) + dotn<NF4>(m1.a, xb);
-        float g = dotn<NF4>(m0.b, xa) + dotn<NF4>(m1.b, xb);
+        v2f acc[4];
+        pair_acc<true>(acc, m0.w, xa);
+        pair_acc<false>(acc, m1.w, xb);
+        const v2f fg = pair_sum(acc);
+        float r = split_dot<0>(m3.w, xb);                          // Wr_prev zl
+        const float f = chan_sum<KQ>(fg.x);
+        const float g = chan_sum<KQ>(fg.y);
         r = chan_sum<KQ>(r);
-        f = chan_sum<KQ>(f);
-        g = chan_sum<KQ>(g);
         if (lead) {
           xv = LDSF(vc, O_XP) + r;               // x_0 (br_prev already inside xp)
           LDSF(vc, O_X0) = xv;
@@ -346,27 +399,32 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       lds_barrier();
       MVN_FINE(b, s, ts - a.t_begin, 2, 0);
       // ---- phase 1
-      float b2f = 0.f, b2g = 0.f;  // chain: (Wc_2 Wr_0) z_0, this thread's 16 inputs
+      v2f b2 = {0.f, 0.f};  // chain: (Wc_2 Wr_0) z_0, this thread's 16 inputs
       if (chain) {
         f4 xz[NF4];
         ldsv<NF4>(xz, vq, O_Z0);
-        float f = dotn<NF4>(m2.a, xz), g = dotn<NF4>(m2.b, xz);
-        f = chan_sum<KQ>(f) + (LDSF(vc, O_B1) + pf[1]);
-        g = chan_sum<KQ>(g) + (LDSF(vc, O_B1 + C) + pg[1]);
+        v2f acc[4], acc2[4];
+        pair_acc<true>(acc, m2.w, xz);
+        pair_acc<true>(acc2, m4.w, xz);  // (same block as the first: the broadcasts fold into op_sel)
+        const v2f fg = pair_sum(acc);
+        b2 = pair_sum(acc2);
+        asm volatile("" : "+v"(b2));  // not to be sunk past the gate (into a block where the broadcasts become moves)
+        const float f = chan_sum<KQ>(fg.x) + (LDSF(vc, O_B1) + pf[1]);
+        const float g = chan_sum<KQ>(fg.y) + (LDSF(vc, O_B1 + C) + pg[1]);
         const float z = gate_fast(f, g);
         if (lead) LDSF(vc, O_Z1) = z;
-        b2f = dotn<NF4>(m4.a, xz);
-        b2g = dotn<NF4>(m4.b, xz);
         MVN_FINE(b, s, ts - a.t_begin, 3, 0);
       } else {
         f4 xa[NF4], xz[NF4];
         ldsv<NF4>(xa, vq, O_X0);
         ldsv<NF4>(xz, vq, O_Z0);
         const float br0 = LDSF(vc, O_VEC + V_BR0);
-        float f = dotn<NF4>(m2.a, xa), g = dotn<NF4>(m2.b, xa);    // Wc_2 x_0
-        float r = dotn<NF4>(m3.b, xz);                             // Wr_0 z_0
-        f = chan_sum<KQ>(f);
-        g = chan_sum<KQ>(g);
+        v2f acc[4];
+        pair_acc<true>(acc, m2.w, xa);                             // Wc_2 x_0
+        const v2f fg = pair_sum(acc);
+        float r = split_dot<1>(m3.w, xz);                          // Wr_0 z_0
+        const float f = chan_sum<KQ>(fg.x);
+        const float g = chan_sum<KQ>(fg.y);
         r = chan_sum<KQ>(r);
         if (lead) {
           LDSF(vc, O_B2) = f;
@@ -382,29 +440,31 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       if (chain) {
         f4 xz[NF4];
         ldsv<NF4>(xz, vq, O_Z1);
-        float f = dotn<NF4>(m3.a, xz) + b2f, g = dotn<NF4>(m3.b, xz) + b2g;
-        f = chan_sum<KQ>(f) + (LDSF(vc, O_B2) + pf[2]);
-        g = chan_sum<KQ>(g) + (LDSF(vc, O_B2 + C) + pg[2]);
+        v2f acc[4];
+        pair_acc<true>(acc, m3.w, xz);
+        const v2f fg = pair_sum(acc) + b2;
+        const float f = chan_sum<KQ>(fg.x) + (LDSF(vc, O_B2) + pf[2]);
+        const float g = chan_sum<KQ>(fg.y) + (LDSF(vc, O_B2 + C) + pg[2]);
         const float z = gate_fast(f, g);
         if (lead) put_granule(ob + C, epoch, z, fast_edge);
         MVN_FINE(b, s, ts - a.t_begin, 5, 0);
       } else {
         f4 xz[NF4];
         ldsv<NF4>(xz, vq, O_Z1);
-        const float br12 = LDSF(vc, O_VEC + V_BR1), br2 = LDSF(vc, O_VEC + V_BR2);
-        float r = dotn<NF4>(m4.a, xz);                             // Wr_1 z_1
+        const float br1 = LDSF(vc, O_VEC + V_BR1), br2 = LDSF(vc, O_VEC + V_BR2);
+        float r = split_dot<0>(m4.w, xz);                          // Wr_1 z_1
         r = chan_sum<KQ>(r);
         if (lead) {
-          xv = (xv + br12) + r;          // x_2
+          xv = (xv + br1) + r;          // x_2
           xs[2] = xv;
           put_granule(ob, epoch, xv + br2, fast_edge);
         }
         // skip lane: sk' = sk + (Ws_prev zl + bs_prev) + (Ws_0 z_0 + bs_0) + (Ws_1 z_1 + bs_1)
-        float k1 = dotn<NF4>(m4.b, xz);
+        float k1 = split_dot<1>(m4.w, xz);
         unsigned wss = lds_addr(lmat + 3 * MAT_F) + 16u * t;  // SS = {Ws_prev; Ws_0}
         asm volatile("" : "+v"(wss));
-        float kp = dot_stream_a<NF4>(wss, vq + 4u * O_ZL);
-        float k0 = dot_stream_a<NF4>(wss + 4096u * NF4, vq + 4u * O_Z0);
+        float kp = split_dot_lds<0>(wss, vq + 4u * O_ZL);
+        float k0 = split_dot_lds<1>(wss, vq + 4u * O_Z0);
         kp = chan_sum<KQ>(kp);
         k0 = chan_sum<KQ>(k0);
         k1 = chan_sum<KQ>(k1);
@@ -604,10 +664,14 @@ __global__ void pack_fold_stage_kernel(FoldLayers p, float *__restrict__ dst) {
     return;
   }
   // matrix element in the per-thread order: [2 NF4][t (256)] float4; thread t = 4c + kq owns rows
-  // (c, C + c) x inputs k = 16 kq + 4 (i4 % NF4) + e
+  // (c, C + c) x inputs 16 kq .. 16 kq + 15 (FoldMat)
   const int mat = i / MAT_F, r = i - mat * MAT_F;
   const int e = r & 3, v4 = r >> 2, t = v4 & 255, i4 = v4 >> 8;
-  const int row = (i4 / NF4) * C + t / KQ, k = KPER * (t % KQ) + 4 * (i4 % NF4) + e;
+  const bool split = mat == M_RR || mat == M_RS || mat == M_SS;
+  // SPLIT: float4 i4 of half i4 / 4 holds inputs 4 (i4 % 4) + e of row t / KQ;
+  // PAIR: float4 i4 holds {row c, row C + c} at inputs 2 i4 and 2 i4 + 1
+  const int row = split ? (i4 / NF4) * C + t / KQ : (e & 1) * C + t / KQ;
+  const int k = KPER * (t % KQ) + (split ? 4 * (i4 % NF4) + e : 2 * i4 + (e >> 1));
   double v = 0.0;
   auto prod = [&](int jc, int jr) {  // (Wc_jc Wr_jr)[row][k]
     double acc = 0.0;
