@@ -60,29 +60,90 @@ __device__ __forceinline__ void put_granule(u64 *g, unsigned epoch, float v, boo
 // 16-byte aligned load never tears an 8-byte store.  Returns false on time-out / raised
 // error word (wave-uniform).
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Two granules (16 bytes at p, per lane) polled with TWO loads in flight: a poll samples L2
+// every half round trip instead of every whole one, which takes ~0.4 round trips off the
+// expected detection delay of a hop.  The loop lives in one asm block on fixed registers
+// (v240-v247, clobbered): registers with a load in flight must never be copied or renamed by
+// the compiler, which a loop-carried C variable cannot promise.  Wave-uniform result: 1 when
+// both epochs match in every active lane (v0, v1 = the values), 0 after 64 double polls.
+__device__ __forceinline__ int poll16(const u64 *p, unsigned epoch, float &v0, float &v1) {
+  int st;
+  unsigned r0, r1;
+  u64 tmp;  // lane mask scratch
+  asm volatile(
+      "s_movk_i32 %[st], 64\n\t"
+      "global_load_dwordx4 v[240:243], %[p], off sc1\n"
+      "1:\n\t"
+      "global_load_dwordx4 v[244:247], %[p], off sc1\n\t"
+      "s_waitcnt vmcnt(1)\n\t"
+      "v_cmp_eq_u32 vcc, %[ep], v241\n\t"
+      "v_cmp_eq_u32 %[t], %[ep], v243\n\t"
+      "s_and_b64 vcc, vcc, %[t]\n\t"
+      "s_cmp_eq_u64 vcc, exec\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "global_load_dwordx4 v[240:243], %[p], off sc1\n\t"
+      "s_waitcnt vmcnt(1)\n\t"
+      "v_cmp_eq_u32 vcc, %[ep], v245\n\t"
+      "v_cmp_eq_u32 %[t], %[ep], v247\n\t"
+      "s_and_b64 vcc, vcc, %[t]\n\t"
+      "s_cmp_eq_u64 vcc, exec\n\t"
+      "s_cbranch_scc1 3f\n\t"
+      "s_sub_u32 %[st], %[st], 1\n\t"
+      "s_cmp_lg_u32 %[st], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b32 %[st], 0\n\t"
+      "s_branch 4f\n"
+      "2:\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "v_mov_b32 %[r0], v240\n\t"
+      "v_mov_b32 %[r1], v242\n\t"
+      "s_mov_b32 %[st], 1\n\t"
+      "s_branch 4f\n"
+      "3:\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "v_mov_b32 %[r0], v244\n\t"
+      "v_mov_b32 %[r1], v246\n\t"
+      "s_mov_b32 %[st], 1\n"
+      "4:\n"
+      : [st] "=&s"(st), [r0] "=&v"(r0), [r1] "=&v"(r1), [t] "=&s"(tmp)
+      : [p] "v"(p), [ep] "s"(epoch)
+      : "vcc", "scc", "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+  v0 = __uint_as_float(r0);
+  v1 = __uint_as_float(r1);
+  return st;
+}
+// The bounded wait around poll16(): false on time-out / raised error word (wave-uniform).
+__device__ __forceinline__ bool wait16(const u64 *p, unsigned epoch, unsigned *err, float &v0, float &v1) {
+  for (unsigned calls = 1;; ++calls) {
+    if (poll16(p, epoch, v0, v1)) return true;
+    const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e != 0 || calls > PIPE_SPIN_LIMIT / 128) {
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+}
+
 template <int GL>
 __device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsigned *err,
                                            float (&v)[GL]) {
   static_assert(GL == 2 || GL == 4, "one or two 16-byte loads per lane");
   const int lane = threadIdx.x & 63;
   const u64 *p = in + 2 * lane;
+  if (GL == 2) return wait16(p, epoch, err, v[0], v[1]);
   for (unsigned spins = 1;; ++spins) {
-    v4u g0, g1 = {0u, epoch, 0u, epoch};
-    if (GL == 2)
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(g0) : "v"(p) : "memory");
-    else
-      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                   "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(g0), "=&v"(g1) : "v"(p) : "memory");
+    v4u g0, g1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(g0), "=&v"(g1) : "v"(p) : "memory");
     const bool ok = g0.y == epoch && g0.w == epoch && g1.y == epoch && g1.w == epoch;
     if (__all(ok)) {
       v[0] = __uint_as_float(g0.x);
       v[1] = __uint_as_float(g0.z);
-      if (GL == 4) {
-        v[GL - 2] = __uint_as_float(g1.x);
-        v[GL - 1] = __uint_as_float(g1.z);
-      }
+      v[GL - 2] = __uint_as_float(g1.x);
+      v[GL - 1] = __uint_as_float(g1.z);
       return true;
     }
     if ((spins & 255u) == 0) {
@@ -99,26 +160,7 @@ __device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsign
 // 64 granules (512 bytes) of an inbox: lanes 0-31 take two each with one 16-byte load (lanes
 // 32-63 repeat them).  v[0], v[1] = granules 2 (lane & 31), + 1 of `in`.  Wave-uniform result.
 __device__ __forceinline__ bool wait_inbox64(const u64 *in, unsigned epoch, unsigned *err, float (&v)[2]) {
-  const int lane = threadIdx.x & 63;
-  const u64 *p = in + 2 * (lane & 31);
-  for (unsigned spins = 1;; ++spins) {
-    v4u g0;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g0) : "v"(p) : "memory");
-    const bool ok = g0.y == epoch && g0.w == epoch;
-    if (__all(ok)) {
-      v[0] = __uint_as_float(g0.x);
-      v[1] = __uint_as_float(g0.z);
-      return true;
-    }
-    if ((spins & 255u) == 0) {
-      const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
+  return wait16(in + 2 * (threadIdx.x & 31), epoch, err, v[0], v[1]);
 }
 
 // ---- cross-lane moves as DPP (one VALU op) instead of ds_bpermute (an LDS round trip)
