@@ -41,9 +41,11 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (vector)" = "Peak FP
 # HBM-side bytes per generated sample per sequence of gen_pipe_kernel<64>, from separate
 # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an earlier run of this same command; NOT
 # measured by the run that prints the line (roofline.traffic_source says so)
-PMC_TRAFFIC = {"bytes_per_step_seq": (19818.3 + 15008.8) * 1024 / (16 * 16000),
-               "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19818 KiB + WRITE_SIZE "
-                         "15009 KiB per 16000-step launch of 16 sequences)"}
+PMC_TRAFFIC = {
+    3: {"bytes_per_step_seq": (19818.3 + 15008.8) * 1024 / (16 * 16000),
+        "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19818 KiB + WRITE_SIZE "
+                  "15009 KiB per 16000-step launch of 16 sequences)"},
+}
 
 
 def flop_per_sample(cfg) -> int:
@@ -445,9 +447,11 @@ def main():
                 # HBM-side bytes per launch: FETCH_SIZE (as reported: 4/8-byte accesses, the
                 # guide's x2 correction is calibrated for 16-B streams only) + WRITE_SIZE of
                 # separate rocprofv3 --pmc passes, scaled to this launch
-                "traffic": (PMC_TRAFFIC["bytes_per_step_seq"] * BATCH * n_new) if variant_used == 3 else None,
-                "traffic_source": (f"constant from {PMC_TRAFFIC['source']} (earlier --pmc passes of this "
-                                   "command); not measured by this run") if variant_used == 3 else None,
+                "traffic": (PMC_TRAFFIC[variant_used]["bytes_per_step_seq"] * BATCH * n_new
+                            if variant_used in PMC_TRAFFIC else None),
+                "traffic_source": (f"constant from {PMC_TRAFFIC[variant_used]['source']} (earlier --pmc passes "
+                                   "of this command); not measured by this run"
+                                   if variant_used in PMC_TRAFFIC else None),
                 "traffic_unit": "bytes per launch (HBM side; the 12.6 MB of dilation queues stay in L2/MALL)",
                 "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>",
                            5: "gen_fold_kernel"}[variant_used],

@@ -746,10 +746,9 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   const bool fold_fits =
       mvn::fold_ok(dims) && batch >= 1 && device_cus() >= 256 && batch <= mvn::fold_max_batch(dims);
   if (requested == MVN_GEN_AUTO) {
-    // (MVN_GEN_FOLD is never chosen here: measured 18.6 us per step against PIPE's 17.9 at
-    // config 2 -- its helper waves' extra products and two more hops cost what the halved
-    // chain saves)
-    (void)fold_fits;
+    // FOLD where it holds the batch (config 2: 15.0 us per step against PIPE's 17.5; at most
+    // 16 sequences), PIPE above that (24); DESIGN.md section 4.1
+    if (fold_fits) return MVN_GEN_FOLD;
     if (pipe_fits) return MVN_GEN_PIPE;
     return mvn::stream_ok(dims) ? MVN_GEN_STREAM : MVN_GEN_GENERIC;
   }

@@ -229,30 +229,41 @@ class RingGenerator:
         return choices, logits
 
 
+# measured microseconds per generated sample-step of ONE launch (any number of co-resident
+# sequences up to the variant's limit); keys: (C, variant)
+_T_STEP_US = {(64, N.GEN_FOLD): 15.0, (64, N.GEN_PIPE): 17.5, (128, N.GEN_PIPE): 79.0}
+# ... and of the best kernel that takes EVERY sequence in one launch; keys: (C, conditioned):
+# STREAM at C=64 without conditioning, GENERIC otherwise
+_T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128, True): 490.0}
+
+
 def auto_plan(dims, batch: int, has_context: bool):
     """What MVN_GEN_AUTO means at the Python level for ``batch`` sequences: returns
-    ("single", variant) for one launch or ("grouped", group) for groups of ``group``
-    sequences taking turns on the PIPE pipelines.
+    ``("single", 0, variant)`` for one launch or ``("grouped", group, variant)`` for groups of
+    ``group`` sequences taking turns on the pipelines of a pipelined variant.
 
-    Chosen on measured per-step cost: a PIPE step costs the same for
-    1..group sequences, so n groups cost n x t_pipe per step of all of them, against ONE
-    launch of the next-best kernel that holds every sequence:
-      C=K=64  : t_pipe 17.6 us vs STREAM 78 us    -> grouped up to 4 groups (96 sequences);
-                with conditioning STREAM does not exist, the alternative is GENERIC
-                (~0.3 ms per step): grouped up to 16 groups;
-      C=K=128 : t_pipe 79 us vs GENERIC 490 us    -> grouped up to 6 groups (24 sequences)."""
+    Chosen on measured per-step cost: a pipelined step costs the same for 1..group sequences,
+    so n groups cost n x t per step of all of them, against ONE launch of the best kernel that
+    holds every sequence (C=K=64: FOLD 15.0 us for up to 16, PIPE 17.5 us for up to 24, STREAM
+    78 us / conditioned GENERIC ~0.3 ms for any number; C=K=128: PIPE 79 us for up to 4,
+    GENERIC 490 us).  Config 2: 1-16 FOLD, 17-24 PIPE, 25-32 two FOLD groups, 33-96 PIPE
+    groups, STREAM beyond (conditioned: PIPE groups up to 16 of them)."""
     lib = N.lib()
-    group = max_pipe_batch(dims)
-    if group <= 0 or batch <= group:
-        return "single", N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
-    n_groups = -(-batch // group)
-    if dims.residual_channels == 64:
-        limit = 16 if has_context else 4
-    else:
-        limit = 6
-    if n_groups <= limit:
-        return "grouped", group
-    return "single", N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
+    single = N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
+    if single in N.PIPE_VARIANTS:
+        return "single", 0, single
+    C = dims.residual_channels
+    best = None
+    for variant in (N.GEN_FOLD, N.GEN_PIPE):
+        t, group = _T_STEP_US.get((C, variant)), max_pipe_batch(dims, variant)
+        if t is None or group <= 0:
+            continue
+        cost = -(-batch // group) * t
+        if best is None or cost < best[0]:
+            best = (cost, group, variant)
+    if best is not None and best[0] < _T_SINGLE_US.get((C, bool(has_context)), 0.0):
+        return "grouped", best[1], best[2]
+    return "single", 0, single
 
 
 def max_pipe_batch(dims, variant: int = N.GEN_PIPE) -> int:

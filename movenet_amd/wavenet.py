@@ -264,14 +264,13 @@ class WaveNet(nn.Module):
 
         with torch.cuda.device(audio.device):
             if self._gen_variant == N.GEN_AUTO:
-                kind, what = auto_plan(self._dims, idx.shape[0], context is not None)
-                pipe = N.GEN_PIPE
+                kind, group, variant = auto_plan(self._dims, idx.shape[0], context is not None)
             else:
-                kind, what, pipe = "single", self._gen_variant, self._gen_variant
-                if pipe == N.GEN_PIPE_F16 and idx.shape[0] > max_pipe_batch(self._dims, pipe):
-                    kind, what = "grouped", max_pipe_batch(self._dims, pipe)  # groups take turns
+                kind, group, variant = "single", 0, self._gen_variant
+                if variant == N.GEN_PIPE_F16 and idx.shape[0] > max_pipe_batch(self._dims, variant):
+                    kind, group = "grouped", max_pipe_batch(self._dims, variant)  # groups take turns
         try:
-            gen = run(what, 0) if kind == "single" else run(pipe, what)
+            gen = run(variant, group if kind == "grouped" else 0)
         except PipeHandoffTimeout:
             # the pipelined kernel needs all its stages co-resident and something else held
             # CUs: rerun THIS call (same prompt, same seed) on a kernel without hand-offs

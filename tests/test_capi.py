@@ -45,7 +45,8 @@ def test_generate_sizes_and_variants():
     lib = N.lib()
     d2 = N.make_dims(10, 3, 256, 64, 64)
     # 16 sequences x 9 pipeline stages fit the 256 CUs; 64 sequences do not
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 17) == N.GEN_PIPE
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 64) == N.GEN_STREAM
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 64) == N.MVN_ERR_UNSUPPORTED
     # one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all

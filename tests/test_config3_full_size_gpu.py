@@ -110,7 +110,7 @@ def test_config3_generate_properties(model):
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_GENERIC])
     assert torch.equal(runs[N.GEN_FOLD], runs[N.GEN_GENERIC])
-    assert torch.equal(runs[N.GEN_PIPE], idx)  # what WaveNet.generate ran
+    assert torch.equal(runs[N.GEN_FOLD], idx)  # what WaveNet.generate ran
     g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + n_new, device=DEV,
                       variant=N.GEN_GENERIC, temperature=0.0, context=ctx)
     choices, _ = g.teacher_forced(idx, logits_t0=rf)

@@ -150,7 +150,7 @@ def test_config2_full_size_properties():
     assert torch.equal(runs[N.GEN_GENERIC], runs[N.GEN_STREAM])
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
     assert torch.equal(runs[N.GEN_FOLD], runs[N.GEN_STREAM])
-    assert _gen(cfg, sd, B, rf + 1).variant == N.GEN_PIPE  # what AUTO runs at config 2
+    assert _gen(cfg, sd, B, rf + 1).variant == N.GEN_FOLD  # what AUTO runs at config 2, batch 16
     g = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_STREAM)
     choices, logits = g.teacher_forced(runs[N.GEN_STREAM], logits_t0=rf)
     assert torch.equal(choices[:, rf:], runs[N.GEN_STREAM][:, rf:])
@@ -441,7 +441,7 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
 
     monkeypatch.setattr(G.RingGenerator, "advance", advance)
     got = model.generate(prompt, n_samples=rf + n_new, temperature=0.0)
-    assert poked == [N.GEN_PIPE] and model.last_generate_fallback == N.GEN_STREAM
+    assert poked == [N.GEN_FOLD] and model.last_generate_fallback == N.GEN_STREAM
     assert torch.equal(got, want)
     # a variant forced by the caller that cannot be rerun differently still never returns
     # silently: the generator's own check raises
@@ -455,12 +455,13 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
 def test_auto_plan_cost_based():
     from movenet_amd.generation import auto_plan
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
-    assert auto_plan(d2, 16, False) == ("single", N.GEN_PIPE)
-    assert auto_plan(d2, 20, False) == ("single", N.GEN_PIPE)
-    assert auto_plan(d2, 64, False) == ("grouped", 24)
-    assert auto_plan(d2, 96, False) == ("grouped", 24)
-    assert auto_plan(d2, 97, False) == ("single", N.GEN_STREAM)   # 5 x 17.6 us > 78 us
-    assert auto_plan(d2, 256, True) == ("grouped", 24)            # no conditioned STREAM kernel
-    assert auto_plan(d5, 4, False) == ("single", N.GEN_PIPE)
-    assert auto_plan(d5, 24, False) == ("grouped", 4)
-    assert auto_plan(d5, 25, False) == ("single", N.GEN_GENERIC)
+    assert auto_plan(d2, 16, False) == ("single", 0, N.GEN_FOLD)
+    assert auto_plan(d2, 20, False) == ("single", 0, N.GEN_PIPE)
+    assert auto_plan(d2, 32, False) == ("grouped", 16, N.GEN_FOLD)    # 2 x 15.0 us < 2 x 17.5 us
+    assert auto_plan(d2, 64, False) == ("grouped", 24, N.GEN_PIPE)    # 3 x 17.5 us < 4 x 15.0 us
+    assert auto_plan(d2, 96, False) == ("grouped", 24, N.GEN_PIPE)
+    assert auto_plan(d2, 97, False) == ("single", 0, N.GEN_STREAM)    # 5 x 17.5 us > 78 us
+    assert auto_plan(d2, 256, True) == ("grouped", 24, N.GEN_PIPE)    # no conditioned STREAM kernel
+    assert auto_plan(d5, 4, False) == ("single", 0, N.GEN_PIPE)
+    assert auto_plan(d5, 24, False) == ("grouped", 4, N.GEN_PIPE)
+    assert auto_plan(d5, 25, False) == ("single", 0, N.GEN_GENERIC)
