@@ -112,8 +112,8 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
                           into the filter/gate matrix of layer j+1 (products formed at pack
                           time): ONE dependent mat-vec + gate per layer instead of two; three
                           layers per stage, ceil(L/3)+1 stages (11 for 30 layers), at most 16
-                          sequences co-resident.  Parity-green but NOT faster than PIPE as built
-                          (18.6 vs 17.9 us per step at config 2): never chosen by MVN_GEN_AUTO.  */
+                          sequences co-resident.  15.0 us per step at config 2 against PIPE's
+                          17.5: what MVN_GEN_AUTO runs whenever it holds the batch.              */
 
 /* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
  * variant or a negative error.  The packed weight layout depends on the variant:
