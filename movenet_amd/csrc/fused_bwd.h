@@ -1,0 +1,235 @@
+// Backward of one gated residual layer, first half, as ONE kernel (C = K = 64, audio only):
+//   dz   = Wr^T dxo + Ws^T dskip                       (B3 of sequence.hip, reference arithmetic
+//   df   = dz sg (1 - th^2),  dg = dz th sg (1 - sg)    movenet/modules.py:79-93 differentiated)
+//   dWr += dxo z^T,  dWs += dskip z^T,  dbr += sum_t dxo,  dbs += sum_t dskip     (z = th sg)
+//
+// The two-kernel form (gemm_wx_staged_kernel<DzOp> beside wgrad2_kernel<WgRsOp, 1> on a second
+// stream) reads dxo, dskip, tanh and sigmoid TWICE: 370 + 306 MB per layer at config 2, both
+// kernels at 3.6-3.8 TB/s of HBM traffic and 20-30 % matrix-core utilisation
+// (profiles/r02_pmc_summary.json) -- bound by the bytes.  Here a workgroup stages a tile
+// [dxo; dskip] (128 rows x 64 time steps), tanh and sigmoid (64 x 64 each) ONCE and runs both
+// products on it:
+//   * dz in TRANSPOSED form, D'[t][c] = sum_o drs[o][t] W[o][c]: the A operand is the staged
+//     tile read along t (one ds_read_b32 per MFMA), the B operand W lives in REGISTERS for the
+//     whole launch (wave (wt, wc) owns a 32 x 32 block of D': 64 values per lane);
+//   * the weight gradient exactly as wgrad2_kernel does it (row-major tiles of pitch 68, four
+//     k-steps per ds_read_b128), z formed on the fly from the tanh and sigmoid tiles;
+//   * the gate derivative in registers (a lane holds 4 x 4 consecutive t of one channel), df | dg
+//     through the staging tile as whole-row float4 stores.
+// Per-workgroup partial tiles and bias sums leave in wgrad2's slab format: the same
+// slab_reduce_kernel / bias_reduce_kernel finish the job (fixed order: deterministic).
+#pragma once
+#include "common.h"
+#include "gemm_family.h"
+
+namespace mvn {
+
+struct FusedBwdAArgs {
+  int t_begin, t_end, t_skip0, t_base;  // t_begin = A_{l+1}: the layer's outputs cover [t_begin, t_end)
+  const float *wr, *ws;                 // (64 out, 64 in) each
+  Act dxo, dskip, th, sg, dfg;          // dxo.p == NULL: last layer (its residual output is unused)
+};
+
+constexpr int FB_C = 64;
+
+__global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, int chunks_per_b,
+                                                              float *__restrict__ bias_part,
+                                                              float *__restrict__ part) {
+  constexpr int C = FB_C, LD = W2_LD, TT = W2_T;
+  __shared__ __attribute__((aligned(16))) float As[2 * C][LD];  // dxo rows | dskip rows; later df | dg
+  __shared__ __attribute__((aligned(16))) float Th[C][LD];
+  __shared__ __attribute__((aligned(16))) float Sg[C][LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
+  const int tb = (a.t_begin & ~3) + ch * W2_CHUNK, te = min(a.t_end, tb + W2_CHUNK);
+  const int skip_lo = max(a.t_begin, a.t_skip0);
+  const bool has_dxo = a.dxo.p != nullptr;
+
+  // ---- B operand of the dz product: W[o][32 wc + li] for o = 2 kk + lh, in registers
+  const int wt = wave >> 1, wc = wave & 1;  // dz block: t in [32 wt, +32), c in [32 wc, +32)
+  float wreg[C];
+#pragma unroll
+  for (int kk = 0; kk < C; ++kk) {
+    const int o = 2 * kk + lh;
+    wreg[kk] = o < C ? (has_dxo ? a.wr[(size_t)o * C + 32 * wc + li] : 0.f)
+                     : a.ws[(size_t)(o - C) * C + 32 * wc + li];
+  }
+  // weight-gradient block of this wave (as wgrad2_kernel<.., 1>): rows [64 wm, +64), cols [32 wn, +32)
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 accw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+
+  // ---- staging: thread -> rows (tid >> 4) + 16 p, columns 4 (tid & 15) .. +3
+  const int srow = tid >> 4, st = 4 * (tid & 15);
+  f4 areg[8], treg[4], sreg[4];
+  float bsum[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
+  unsigned azero = 0;
+  auto gload = [&](int t0) {
+    int srow_q = srow;
+    asm volatile("" : "+v"(srow_q));
+    const int t = t0 + st;
+    // the tile lies inside every live row's range (one test per tile, workgroup-uniform):
+    // sixteen back-to-back 16-byte loads; rows whose range misses the tile altogether (dskip
+    // before t_skip0, the absent dxo of the last layer) load a row that IS valid and are zeroed
+    // at the LDS store
+    const bool x_full = t0 >= a.t_begin && t0 + TT <= te;
+    const bool s_full = t0 >= skip_lo && t0 + TT <= te, s_none = t0 + TT <= skip_lo;
+    azero = (has_dxo ? 0u : 0x0Fu) | (s_none ? 0xF0u : 0u);
+    if (x_full && (s_full || s_none)) {
+      const float *t0p = a.th.at(b, srow_q, 0) + t;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const float *q = ((azero >> p) & 1u) ? t0p
+                         : p < 4           ? a.dxo.at(b, 16 * p + srow_q, 0) + t
+                                           : a.dskip.at(b, 16 * (p - 4) + srow_q, 0) + (t - a.t_base);
+        areg[p] = ldg4(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        treg[p] = ldg4(a.th.at(b, 16 * p + srow_q, 0) + t);
+        sreg[p] = ldg4(a.sg.at(b, 16 * p + srow_q, 0) + t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        if (p < 4)
+          areg[p] = has_dxo ? ld4_edge(a.dxo.at(b, 16 * p + srow_q, 0), t, a.t_begin, te) : kZero4;
+        else
+          areg[p] = ld4_edge(a.dskip.at(b, 16 * (p - 4) + srow_q, 0) - a.t_base, t, skip_lo, te);
+      }
+      azero = 0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        treg[p] = ld4_edge(a.th.at(b, 16 * p + srow_q, 0), t, a.t_begin, te);
+        sreg[p] = ld4_edge(a.sg.at(b, 16 * p + srow_q, 0), t, a.t_begin, te);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      if ((azero >> p) & 1u) areg[p] = kZero4;
+      *(f4 *)&As[16 * p + srow][st] = areg[p];
+      bsum[p] += (areg[p].x + areg[p].y) + (areg[p].z + areg[p].w);  // bias gradient = row sums
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *(f4 *)&Th[16 * p + srow][st] = treg[p];
+      *(f4 *)&Sg[16 * p + srow][st] = sreg[p];
+    }
+  };
+
+  gload(tb);
+  lstore();
+  __syncthreads();
+  for (int t0 = tb; t0 < te; t0 += TT) {
+    const bool more = t0 + TT < te;
+    if (more) gload(t0 + TT);  // the next tile's loads fly under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dz' (32 t x 32 c) = sum over the 128 rows of the tile
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk)
+      accd = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
+    // ---- weight gradient: (64 x 32) += A (64 x 64 t) z^T
+#pragma unroll
+    for (int g = 0; g < TT / 8; ++g) {
+      f4 av[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) av[mi] = *(const f4 *)&As[64 * wm + 32 * mi + li][8 * g + h4];
+      const f4 tv = *(const f4 *)&Th[32 * wn + li][8 * g + h4], sv = *(const f4 *)&Sg[32 * wn + li][8 * g + h4];
+      const f4 zv = f4{tv.x * sv.x, tv.y * sv.y, tv.z * sv.z, tv.w * sv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          accw[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[mi], j), f4_get(zv, j), accw[mi], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave has read the tile: As becomes the df | dg staging tile
+    // ---- gate derivative: this lane holds dz of channel 32 wc + li at t = 32 wt + 8 q + 4 lh + e
+    // (after the barrier, straight into the staging tile: held in registers across it, the 32
+    // values spilled next to the next tile's 64 staging registers)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tc = 32 * wt + 8 * q + h4;
+      const f4 tv = *(const f4 *)&Th[32 * wc + li][tc], sv = *(const f4 *)&Sg[32 * wc + li][tc];
+      const f4 dz = f4{accd[4 * q], accd[4 * q + 1], accd[4 * q + 2], accd[4 * q + 3]};
+      *(f4 *)&As[32 * wc + li][tc] =
+          f4{dz.x * sv.x * (1.0f - tv.x * tv.x), dz.y * sv.y * (1.0f - tv.y * tv.y),
+             dz.z * sv.z * (1.0f - tv.z * tv.z), dz.w * sv.w * (1.0f - tv.w * tv.w)};
+      *(f4 *)&As[C + 32 * wc + li][tc] =
+          f4{dz.x * tv.x * sv.x * (1.0f - sv.x), dz.y * tv.y * sv.y * (1.0f - sv.y),
+             dz.z * tv.z * sv.z * (1.0f - sv.z), dz.w * tv.w * sv.w * (1.0f - sv.w)};
+    }
+    __syncthreads();
+    {
+      // whole-row float4 stores: rows 16 p + srow, columns t0 + st .. +3, inside [t_begin, te)
+      const int t = t0 + st;
+      float *base = a.dfg.p + (size_t)b * a.dfg.sb + t;
+      if (t >= a.t_begin && t + 3 < te) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          *(f4 *)(base + (size_t)(16 * p + srow) * a.dfg.ld) = *(const f4 *)&As[16 * p + srow][st];
+      } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t + e >= a.t_begin && t + e < te) base[(size_t)(16 * p + srow) * a.dfg.ld + e] = As[16 * p + srow][st + e];
+      }
+    }
+    __syncthreads();
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  // ---- this workgroup's slab and bias partial sums (wgrad2_kernel's format, m_rows_pad 128, n_cols_pad 64)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 64 * wm + 32 * mi + acc_row(r, lane), n = 32 * wn + li;
+      part[((size_t)blockIdx.x * 128 + m) * 64 + n] = accw[mi][r];
+    }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    float v = bsum[p];  // 16 lanes share a row
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if ((tid & 15) == 0) bias_part[(size_t)blockIdx.x * 128 + 16 * p + srow] = v;
+  }
+}
+
+// `op` describes where the gradients go (WgRsOp::dw / db); slab: chunks * batch * 128 * 64 floats,
+// bias_scratch: chunks * batch * 128 floats.  False when the scratch is too small (the caller
+// then runs the two-kernel form).
+template <class WgOp>
+static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int batch, float *bias_scratch,
+                                 float *slab, size_t slab_floats, hipStream_t s) {
+  const int nt = a.t_end - (a.t_begin & ~3);
+  if (a.t_end <= a.t_begin || batch <= 0) return true;
+  const int chunks = (nt + W2_CHUNK - 1) / W2_CHUNK;
+  const size_t need = (size_t)chunks * batch * 128 * 64;
+  if (!bias_scratch || !slab || need > slab_floats) return false;
+  hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, bias_scratch, slab);
+  hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 64 / 32), dim3(256), 0, s, op, slab, chunks * batch, 128, 64);
+  hipLaunchKernelGGL(bias_reduce_kernel<WgOp>, dim3(128), dim3(64), 0, s, op, bias_scratch, chunks * batch, 128);
+  return true;
+}
+
+}  // namespace mvn

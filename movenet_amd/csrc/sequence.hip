@@ -27,6 +27,7 @@
 #include "common.h"
 #include "gemm_family.h"
 #include "fused_layer.h"
+#include "fused_bwd.h"
 
 namespace mvn {
 
@@ -1062,6 +1063,11 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     const char *e = getenv("MOVENET_HIP_NO_SIDE_STREAM");
     return e && e[0] == '1';
   }();
+  // MOVENET_HIP_NO_FUSED_BACKWARD=1: the two-kernel forms (cross-checks, profiling)
+  static const bool fused_bwd = [] {
+    const char *e = getenv("MOVENET_HIP_NO_FUSED_BACKWARD");
+    return !(e && e[0] == '1');
+  }();
   const bool fork = bias_scratch2 && !no_side;
   hipStream_t s2 = s;
   if (fork) {
@@ -1093,17 +1099,31 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     wr.dxo = dxo; wr.dskip = dskip; wr.th = th; wr.sg = sg;
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
-    if (bias_scratch2)
-      launch_wgrad2<1>(wr, C + Kc, C, batch, bias_scratch2, slab, slab_floats, s2);
-    else
-      launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s2);
+    bool fused_a = false;
+    if (fused_bwd && C == 64 && Kc == 64 && !has_ctx && bias_scratch2) {
+      // dz and the residual/skip weight gradients from ONE pass over dxo, dskip, tanh, sigmoid
+      // (fused_bwd.h); on the main stream: the side stream only keeps the filter/gate gradient
+      FusedBwdAArgs fa;
+      fa.t_begin = t_lo; fa.t_end = T; fa.t_skip0 = t_skip0; fa.t_base = g.t_base;
+      fa.wr = p->residual_w[l]; fa.ws = p->skip_w[l];
+      fa.dxo = dxo; fa.dskip = dskip; fa.th = th; fa.sg = sg; fa.dfg = dfg;
+      fused_a = launch_bwd_dz_wgrs64(fa, wr, batch, bias_scratch2, slab, slab_floats, s);
+    }
+    if (!fused_a) {
+      if (bias_scratch2)
+        launch_wgrad2<1>(wr, C + Kc, C, batch, bias_scratch2, slab, slab_floats, s2);
+      else
+        launch_wgrad(wr, C + Kc, C, batch, bias_scratch, s2);
+    }
     signal(2, s2);
-    DzOp dz;
-    dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
-    dz.t_base = g.t_base;
-    dz.wr = p->residual_w[l]; dz.ws = p->skip_w[l];
-    dz.dxo = dxo; dz.dskip = dskip; dz.th = th; dz.sg = sg; dz.dfg = dfg;
-    launch_gemm_staged(dz, C, batch, s);
+    if (!fused_a) {
+      DzOp dz;
+      dz.K = C + Kc; dz.t_begin = t_lo; dz.t_end = T; dz.C = C; dz.Kc = Kc; dz.t_skip0 = t_skip0;
+      dz.t_base = g.t_base;
+      dz.wr = p->residual_w[l]; dz.ws = p->skip_w[l];
+      dz.dxo = dxo; dz.dskip = dskip; dz.th = th; dz.sg = sg; dz.dfg = dfg;
+      launch_gemm_staged(dz, C, batch, s);
+    }
     signal(1, s);
     await(1, s2);
     auto run_wf = [&](auto wf) {
