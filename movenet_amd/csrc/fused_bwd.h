@@ -232,4 +232,209 @@ static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int bat
   return true;
 }
 
+// ----------------------------------------------------------------------------------------
+// Second half: the gradient w.r.t. the layer input and the filter/gate weight gradients,
+//   dx[u]   = [u >= t_lo] (dxo[u] + W1^T dfg[u]) + [u + d < T] W0^T dfg[u + d]     (B4 of sequence.hip)
+//   dWf|dWg[o][c][tap 1] += dfg[o][t] x[c][t],   [tap 0] += dfg[o][t] x[c][t - d]
+// The two-kernel form (gemm_wx_staged_kernel<DxOp> beside wgrad2_kernel<WgFgOpT, 2>) reads dfg
+// three times (389 + 290 MB per layer).  Here a 512-thread workgroup (one per CU: 102 KB of
+// LDS) stages dfg[t] (128 x 64), dfg[t + d] (128 x 64) and [x(t - d); x(t)] (128 x 64) once per
+// tile; waves 0-3 take the tap-1 half of dx (K = the 128 rows of dfg[t]), waves 4-7 the tap-0
+// half (dfg[t + d]), both in the transposed form of the first half with their 64 weights per
+// lane in registers, and every wave owns two of the sixteen 32 x 32 blocks of the weight
+// gradient.  The two dx halves meet in the staging tiles (the dfg[t + d] buffer) and leave,
+// with dxo added, as whole-row float4 stores.
+// Tiles run over u from A_l (& ~3): before t_lo = A_l + d the dfg[t] and x operands are zero
+// (masked loads), which is exactly the [u >= t_lo] of the formula.
+// ----------------------------------------------------------------------------------------
+struct FusedBwdBArgs {
+  int t_out0, t_lo, t_end, d;   // outputs cover [t_out0 = A_l, t_end); t_lo = A_{l+1} = A_l + d
+  const float *wf, *wg;         // (64 out, 64 in, 2 taps) each
+  Act dxo, dfg, xin, dxi;       // dxo.p == NULL: last layer
+};
+
+constexpr int FBB_LDS_FLOATS = 3 * 128 * W2_LD;
+
+__global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, int chunks_per_b,
+                                                              float *__restrict__ part) {
+  constexpr int C = FB_C, LD = W2_LD, TT = W2_T;
+  extern __shared__ __attribute__((aligned(16))) float fbb_lds[];
+  float (*As)[LD] = (float (*)[LD])fbb_lds;                    // dfg[t]      (df rows | dg rows)
+  float (*A2)[LD] = (float (*)[LD])(fbb_lds + 128 * LD);       // dfg[t + d]; later the two dx halves
+  float (*Xs)[LD] = (float (*)[LD])(fbb_lds + 2 * 128 * LD);   // x(t - d) rows | x(t) rows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
+  const int tb = (a.t_out0 & ~3) + ch * W2_CHUNK, te = min(a.t_end, tb + W2_CHUNK);
+  const bool has_dxo = a.dxo.p != nullptr;
+
+  // ---- dx: wave -> (tap half, 32 u x 32 c block); B operand W_tap[o][32 wc + li], o = 2 kk + lh
+  const int half = wave >> 2, wt = (wave >> 1) & 1, wc = wave & 1;
+  float wreg[C];
+#pragma unroll
+  for (int kk = 0; kk < C; ++kk) {
+    const int o = 2 * kk + lh;
+    const float *src = o < C ? a.wf : a.wg;
+    wreg[kk] = src[((size_t)(o & (C - 1)) * C + 32 * wc + li) * 2 + (half ? 0 : 1)];
+  }
+  // ---- weight gradient: wave -> rows [32 (wave >> 1), +32), columns [64 (wave & 1), +64)
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 accw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+
+  // ---- staging: thread -> rows (tid >> 4) + 32 p, columns 4 (tid & 15) .. +3
+  const int srow = tid >> 4, st = 4 * (tid & 15);
+  f4 areg[4], a2reg[4], xreg[4], oreg[2];
+  auto gload = [&](int t0) {
+    int srow_q = srow;
+    asm volatile("" : "+v"(srow_q));
+    const int t = t0 + st;
+    // interior tile: every operand row covers it (dfg[t], x, dxo from t_lo; dfg[t + d] up to T - d)
+    if (t0 >= a.t_lo && t0 + TT + a.d <= a.t_end && t0 + TT <= te) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        areg[p] = ldg4(a.dfg.at(b, 32 * p + srow_q, 0) + t);
+        a2reg[p] = ldg4(a.dfg.at(b, 32 * p + srow_q, 0) + t + a.d);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = 32 * p + srow_q;  // rows [0, 64): x(t - d); [64, 128): x(t)
+        xreg[p] = ldg4(a.xin.at(b, row & (C - 1), 0) + t - (p < 2 ? a.d : 0));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (has_dxo) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) oreg[p] = ldg4(a.dxo.at(b, 32 * p + srow_q, 0) + t);
+      }
+    } else {
+      const int hi = min(a.t_end, te);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        areg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi);
+        // dfg[u + d] for the outputs u of this tile: u < te, u + d < T
+        a2reg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0) + a.d, t, a.t_lo - a.d, min(a.t_end - a.d, te));
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = 32 * p + srow_q;
+        xreg[p] = ld4_edge(a.xin.at(b, row & (C - 1), 0) - (p < 2 ? a.d : 0), t, a.t_lo, hi);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        oreg[p] = has_dxo ? ld4_edge(a.dxo.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi) : kZero4;
+    }
+    if (!has_dxo) oreg[0] = oreg[1] = kZero4;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *(f4 *)&As[32 * p + srow][st] = areg[p];
+      *(f4 *)&A2[32 * p + srow][st] = a2reg[p];
+      *(f4 *)&Xs[32 * p + srow][st] = xreg[p];
+    }
+  };
+
+  gload(tb);
+  lstore();
+  f4 ocur[2] = {oreg[0], oreg[1]};  // dxo of the tile in LDS (the registers take the next tile's)
+  __syncthreads();
+  for (int t0 = tb; t0 < te; t0 += TT) {
+    const bool more = t0 + TT < te;
+    if (more) gload(t0 + TT);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- this wave's half of dx' (32 u x 32 c)
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+    {
+      float (*src)[LD] = half ? A2 : As;
+#pragma unroll
+      for (int kk = 0; kk < C; ++kk)
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(src[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
+    }
+    // ---- weight gradient: (32 x 64) += dfg (32 x 64 t) [x(t - d); x(t)]^T
+#pragma unroll
+    for (int g = 0; g < TT / 8; ++g) {
+      const f4 av = *(const f4 *)&As[32 * wm + li][8 * g + h4];
+      f4 xv[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) xv[ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][8 * g + h4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          accw[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av, j), f4_get(xv[ni], j), accw[ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave has read the tiles: A2 becomes the two staging tiles [2][64][LD]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(f4 *)&A2[64 * half + 32 * wc + li][32 * wt + 8 * q + h4] =
+          f4{accd[4 * q], accd[4 * q + 1], accd[4 * q + 2], accd[4 * q + 3]};
+    __syncthreads();
+    {
+      // rows srow + 32 p (p < 2), columns t0 + st .. +3 inside [t_out0, te)
+      const int t = t0 + st;
+      float *base = a.dxi.p + (size_t)b * a.dxi.sb + t;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = 32 * p + srow;
+        const f4 v1 = *(const f4 *)&A2[row][st], v0 = *(const f4 *)&A2[64 + row][st], o = ocur[p];
+        const f4 r = f4{(v1.x + v0.x) + o.x, (v1.y + v0.y) + o.y, (v1.z + v0.z) + o.z, (v1.w + v0.w) + o.w};
+        float *q = base + (size_t)row * a.dxi.ld;
+        if (t >= a.t_out0 && t + 3 < te) {
+          *(f4 *)q = r;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t + e >= a.t_out0 && t + e < te) q[e] = f4_get(r, e);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) {
+      lstore();
+      ocur[0] = oreg[0];
+      ocur[1] = oreg[1];
+      __syncthreads();
+    }
+  }
+  // ---- this workgroup's slab (wgrad2_kernel's format, 128 x 128)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * wm + acc_row(r, lane), n = 64 * wn + 32 * ni + li;
+      part[((size_t)blockIdx.x * 128 + m) * 128 + n] = accw[ni][r];
+    }
+}
+
+// `op`: where the gradients go (WgFgOpT<false>::dw).  slab: chunks * batch * 128 * 128 floats.
+template <class WgOp>
+static int launch_bwd_dx_wgfg64(const FusedBwdBArgs &a, const WgOp &op, int batch, float *slab,
+                                size_t slab_floats, hipStream_t s, bool *done) {
+  *done = false;
+  const int nt = a.t_end - (a.t_out0 & ~3);
+  if (a.t_end <= a.t_out0 || batch <= 0) {
+    *done = true;
+    return MVN_OK;
+  }
+  const int chunks = (nt + W2_CHUNK - 1) / W2_CHUNK;
+  const size_t need = (size_t)chunks * batch * 128 * 128;
+  if (!slab || need > slab_floats) return MVN_OK;
+  const void *fn = (const void *)bwd_dx_wgfg64_kernel;
+  const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(bwd_dx_wgfg64)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd_dx_wgfg64_kernel, dim3(chunks * batch), dim3(512), FBB_LDS_FLOATS * sizeof(float), s, a,
+                     chunks, slab);
+  hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 128 / 32), dim3(256), 0, s, op, slab, chunks * batch, 128, 128);
+  *done = true;
+  return MVN_OK;
+}
+
 }  // namespace mvn

@@ -1125,6 +1125,20 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       launch_gemm_staged(dz, C, batch, s);
     }
     signal(1, s);
+    bool fused_b = false;
+    if (fused_bwd && C == 64 && !has_ctx) {
+      // dx and the filter/gate weight gradients from ONE pass over dfg (fused_bwd.h)
+      FusedBwdBArgs fb;
+      fb.t_out0 = A_lo[l]; fb.t_lo = t_lo; fb.t_end = T; fb.d = d;
+      fb.wf = p->filter_w[l]; fb.wg = p->gate_w[l];
+      fb.dxo = dxo; fb.dfg = dfg; fb.xin = xin; fb.dxi = act_view(cur, batch, C, g.Tp);
+      WgFgOpT<false> wf;
+      wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
+      wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
+      wf.dwcf = nullptr; wf.dwcg = nullptr; wf.dbcf = nullptr; wf.dbcg = nullptr;
+      rc = launch_bwd_dx_wgfg64(fb, wf, batch, slab, slab_floats, s, &fused_b);
+      if (rc) return rc;
+    }
     await(1, s2);
     auto run_wf = [&](auto wf) {
       wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
@@ -1138,7 +1152,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       else
         launch_wgrad(wf, 2 * C, 3 * C, batch, ctx_bias_scratch, s2);
     };
-    if (has_ctx) run_wf(WgFgOpT<true>()); else run_wf(WgFgOpT<false>());
+    if (fused_b) {
+    } else if (has_ctx) run_wf(WgFgOpT<true>()); else run_wf(WgFgOpT<false>());
     signal(3, s2);
     if (has_ctx) {
       DctxOp dc;
@@ -1146,11 +1161,13 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       dc.wcf = p->ctx_filter_w[l]; dc.wcg = p->ctx_gate_w[l]; dc.dfg = dfg; dc.dctx = dctxv;
       launch_gemm_staged(dc, C, batch, s);
     }
-    DxOp dx;
-    dx.K = 4 * C; dx.t_begin = A_lo[l]; dx.t_end = T; dx.C = C; dx.d = d; dx.t_lo = t_lo;
-    dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];
-    dx.dxo = dxo; dx.dfg = dfg; dx.dxi = act_view(cur, batch, C, g.Tp);
-    launch_gemm_staged(dx, C, batch, s);
+    if (!fused_b) {
+      DxOp dx;
+      dx.K = 4 * C; dx.t_begin = A_lo[l]; dx.t_end = T; dx.C = C; dx.d = d; dx.t_lo = t_lo;
+      dx.wf = p->filter_w[l]; dx.wg = p->gate_w[l];
+      dx.dxo = dxo; dx.dfg = dfg; dx.dxi = act_view(cur, batch, C, g.Tp);
+      launch_gemm_staged(dx, C, batch, s);
+    }
     signal(0, s);
     dxo_p = cur;
     float *tmp = cur; cur = nxt; nxt = tmp;
