@@ -1064,7 +1064,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     return e && e[0] == '1';
   }();
   // MOVENET_HIP_NO_FUSED_BACKWARD=1: the two-kernel forms (cross-checks, profiling)
-  static const bool fused_bwd = [] {
+  // (read per call: tests/test_forward_gpu.py runs both forms in one process)
+  const bool fused_bwd = [] {
     const char *e = getenv("MOVENET_HIP_NO_FUSED_BACKWARD");
     return !(e && e[0] == '1');
   }();

@@ -224,3 +224,46 @@ def test_cross_entropy_on_probs_matches_torch_autograd():
     assert acc.item() == (b.argmax(1) == target).float().mean().item()
     assert rel_err(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6
     assert not acc.requires_grad
+
+
+@pytest.mark.parametrize("layers,t_len,batch", [((3, 2), 100, 3), ((10, 1), 1024 + 700 + 37, 2), ((6, 2), 64 * 9 + 1, 1)])
+def test_fused_backward_kernels_match_two_kernel_forms_and_oracle(monkeypatch, layers, t_len, batch):
+    """C = K = 64 takes the fused backward (csrc/fused_bwd.h: dz + residual/skip weight
+    gradients, then dx + filter/gate weight gradients).  Ragged lengths put t_lo, t_skip0 and
+    T inside tiles and leave chunks with a single short tile; the last layer has no dxo.
+    Checked against the two-kernel forms (MOVENET_HIP_NO_FUSED_BACKWARD=1, same process) and,
+    where the oracle finishes in seconds, against torch autograd on the oracle."""
+    from oracle import wavenet_oracle as O
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=layers[0], stack_size=layers[1], input_channels=256, residual_channels=64,
+               skip_channels=64)
+    sd = make_state_dict(**cfg, seed=5, gain=1.5)
+    dims = O.Dims(**cfg)
+    assert t_len > dims.receptive_fields
+    x = one_hot(synthetic_indices(batch, t_len, 256, 77), 256)
+    w = torch.linspace(0.5, 1.5, 256).view(1, 256, 1)
+
+    def grads(no_fused):
+        if no_fused:
+            monkeypatch.setenv("MOVENET_HIP_NO_FUSED_BACKWARD", "1")
+        else:
+            monkeypatch.delenv("MOVENET_HIP_NO_FUSED_BACKWARD", raising=False)
+        m = _model(cfg, sd).train()
+        out = m(x.to(DEV), output_unnormalized=False)
+        (out * w.to(DEV)).square().mean().backward()
+        return {k: (None if p.grad is None else p.grad.cpu()) for k, p in m.named_parameters()}
+
+    fused, plain = grads(False), grads(True)
+    for k in fused:
+        assert (fused[k] is None) == (plain[k] is None), k
+        if fused[k] is not None:
+            assert rel_err(fused[k], plain[k]) < 2e-5, k  # fp32 sums in another order
+    if t_len <= 700:
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out_o = O.forward(params, dims, x, output_unnormalized=False)
+        (out_o * w).square().mean().backward()
+        for k, g in fused.items():
+            if params[k].grad is None:
+                assert g is None, k
+            else:
+                assert rel_err(g, params[k].grad) < 3e-4, k
