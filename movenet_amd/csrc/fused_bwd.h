@@ -157,6 +157,11 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
           accw[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[mi], j), f4_get(zv, j), accw[mi], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // The next tile's loads have had the whole MFMA section to land: wait for them HERE.  On
+    // gfx9 stores count in vmcnt too, and the number of stores below depends on the path (edge
+    // tiles), so the compiler's own wait in front of lstore() was vmcnt(0) -- behind this tile's
+    // global stores, i.e. one full store round trip per tile with the matrix cores idle.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
     __syncthreads();  // every wave has read the tile: As becomes the df | dg staging tile
     // ---- gate derivative: this lane holds dz of channel 32 wc + li at t = 32 wt + 8 q + 4 lh + e
     // (after the barrier, straight into the staging tile: held in registers across it, the 32
@@ -289,46 +294,63 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   // ---- staging: thread -> rows (tid >> 4) + 32 p, columns 4 (tid & 15) .. +3
   const int srow = tid >> 4, st = 4 * (tid & 15);
   f4 areg[4], a2reg[4], xreg[4], oreg[2];
-  auto gload = [&](int t0) {
+  // interior tile: every operand row covers it (dfg[t], x, dxo from t_lo; dfg[t + d] up to T - d)
+  auto interior = [&](int t0) { return t0 >= a.t_lo && t0 + TT + a.d <= a.t_end && t0 + TT <= te; };
+  // The 14 loads of an interior tile are issued in seven parts BETWEEN the MFMA steps of the
+  // tile before: issued in one burst at the top of the tile, the vector-memory pipe of the CU
+  // took ~8 000 cycles to accept them (12 B/clk), the younger wave of every SIMD sat in that
+  // queue while the older one ran its MFMAs alone, and then ran its own alone behind it --
+  // the two waves of a SIMD took turns on the matrix core (in-kernel timers: 24 k cycles per
+  // tile against 16 k of MFMAs).
+  auto gload_part = [&](int t0, int part) {
     int srow_q = srow;
     asm volatile("" : "+v"(srow_q));
     const int t = t0 + st;
-    // interior tile: every operand row covers it (dfg[t], x, dxo from t_lo; dfg[t + d] up to T - d)
-    if (t0 >= a.t_lo && t0 + TT + a.d <= a.t_end && t0 + TT <= te) {
+    if (part < 4) {
+      areg[part] = ldg4(a.dfg.at(b, 32 * part + srow_q, 0) + t);
+      a2reg[part] = ldg4(a.dfg.at(b, 32 * part + srow_q, 0) + t + a.d);
+    } else if (part < 6) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        areg[p] = ldg4(a.dfg.at(b, 32 * p + srow_q, 0) + t);
-        a2reg[p] = ldg4(a.dfg.at(b, 32 * p + srow_q, 0) + t + a.d);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 2 * (part - 4); p < 2 * (part - 4) + 2; ++p) {
         const int row = 32 * p + srow_q;  // rows [0, 64): x(t - d); [64, 128): x(t)
         xreg[p] = ldg4(a.xin.at(b, row & (C - 1), 0) + t - (p < 2 ? a.d : 0));
-        __builtin_amdgcn_sched_barrier(0);
       }
+    } else if (part == 6) {
       if (has_dxo) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) oreg[p] = ldg4(a.dxo.at(b, 32 * p + srow_q, 0) + t);
+      } else {
+        oreg[0] = oreg[1] = kZero4;
       }
-    } else {
-      const int hi = min(a.t_end, te);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        areg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi);
-        // dfg[u + d] for the outputs u of this tile: u < te, u + d < T
-        a2reg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0) + a.d, t, a.t_lo - a.d, min(a.t_end - a.d, te));
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int row = 32 * p + srow_q;
-        xreg[p] = ld4_edge(a.xin.at(b, row & (C - 1), 0) - (p < 2 ? a.d : 0), t, a.t_lo, hi);
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        oreg[p] = has_dxo ? ld4_edge(a.dxo.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi) : kZero4;
     }
-    if (!has_dxo) oreg[0] = oreg[1] = kZero4;
+  };
+  auto gload_edge = [&](int t0) {
+    int srow_q = srow;
+    asm volatile("" : "+v"(srow_q));
+    const int t = t0 + st;
+    const int hi = min(a.t_end, te);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      areg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi);
+      // dfg[u + d] for the outputs u of this tile: u < te, u + d < T
+      a2reg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0) + a.d, t, a.t_lo - a.d, min(a.t_end - a.d, te));
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = 32 * p + srow_q;
+      xreg[p] = ld4_edge(a.xin.at(b, row & (C - 1), 0) - (p < 2 ? a.d : 0), t, a.t_lo, hi);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      oreg[p] = has_dxo ? ld4_edge(a.dxo.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi) : kZero4;
+  };
+  auto gload = [&](int t0) {
+    if (interior(t0)) {
+#pragma unroll
+      for (int part = 0; part < 7; ++part) gload_part(t0, part);
+    } else {
+      gload_edge(t0);
+    }
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -345,32 +367,46 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   __syncthreads();
   for (int t0 = tb; t0 < te; t0 += TT) {
     const bool more = t0 + TT < te;
-    if (more) gload(t0 + TT);
+    const bool spread = more && interior(t0 + TT);
+    if (more && !spread) gload_edge(t0 + TT);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- this wave's half of dx' (32 u x 32 c)
+    // ---- this wave's half of dx' (32 u x 32 c) and its two blocks of the weight gradient, eight
+    // steps of 8 + 8 MFMAs.  The LDS operands of step g + 1 are requested BEFORE the MFMAs of
+    // step g (two statically named register sets): left to the scheduler every pair of MFMAs
+    // waited out the ds_read issued right in front of it.
     f32x16 accd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accd[r] = 0.f;
     {
       float (*src)[LD] = half ? A2 : As;
+      float dv[2][8];
+      f4 av[2], xv[2][2];
+      auto fetch = [&](int g, int S) {
 #pragma unroll
-      for (int kk = 0; kk < C; ++kk)
-        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(src[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
-    }
-    // ---- weight gradient: (32 x 64) += dfg (32 x 64 t) [x(t - d); x(t)]^T
+        for (int i = 0; i < 8; ++i) dv[S][i] = src[2 * (8 * g + i) + lh][32 * wt + li];
+        av[S] = *(const f4 *)&As[32 * wm + li][8 * g + h4];
 #pragma unroll
-    for (int g = 0; g < TT / 8; ++g) {
-      const f4 av = *(const f4 *)&As[32 * wm + li][8 * g + h4];
-      f4 xv[2];
+        for (int ni = 0; ni < 2; ++ni) xv[S][ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][8 * g + h4];
+      };
+      fetch(0, 0);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) xv[ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][8 * g + h4];
+      for (int g = 0; g < TT / 8; ++g) {
+        const int S = g & 1;
+        if (g + 1 < TT / 8) fetch(g + 1, S ^ 1);
+        if (spread) gload_part(t0 + TT, g);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          accw[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av, j), f4_get(xv[ni], j), accw[ni], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[S], j), f4_get(xv[S][0], j), accw[0], 0, 0, 0);
+          accd = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[S][2 * j], wreg[8 * g + 2 * j], accd, 0, 0, 0);
+          accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[S], j), f4_get(xv[S][1], j), accw[1], 0, 0, 0);
+          accd = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[S][2 * j + 1], wreg[8 * g + 2 * j + 1], accd, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores (see the first half)
     __syncthreads();  // every wave has read the tiles: A2 becomes the two staging tiles [2][64][LD]
 #pragma unroll
     for (int q = 0; q < 4; ++q)
