@@ -392,14 +392,10 @@ def main():
     flops_per_launch = flop_per_sample(CFG) * BATCH * n_new
     achieved = flops_per_launch / avg_kernel_s / 1e12
 
-    extras = None
-    if rank == 0 and not args.no_extras:
-        try:
-            extras = extra_lines(dev, sd, rf, n_new, rank)
-            log(f"rank 0: extras {extras}")
-        except Exception as e:
-            extras = {"error": f"{type(e).__name__}: {e}"}
-
+    # (the train leg runs BEFORE the extra generator figures: after their 300 MB one-hot tensors
+    # have come and gone, the same training step takes 21-24 ms instead of 17.5 on the same box --
+    # every HBM-bound kernel slower, the slab reduces 3x -- with or without empty_cache(); device
+    # memory handed back fragmented is our reading, not verified)
     train = None
     if not args.no_train_leg:
         try:
@@ -409,6 +405,14 @@ def main():
             log(f"rank {rank}: train leg {train['value']:.0f} tokens/s")
         except Exception as e:  # the headline metric must survive a failure here
             train = {"error": f"{type(e).__name__}: {e}"}
+
+    extras = None
+    if rank == 0 and not args.no_extras:
+        try:
+            extras = extra_lines(dev, sd, rf, n_new, rank)
+            log(f"rank 0: extras {extras}")
+        except Exception as e:
+            extras = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         out = {
