@@ -465,3 +465,46 @@ def test_auto_plan_cost_based():
     assert auto_plan(d5, 4, False) == ("single", 0, N.GEN_PIPE)
     assert auto_plan(d5, 24, False) == ("grouped", 4, N.GEN_PIPE)
     assert auto_plan(d5, 25, False) == ("single", 0, N.GEN_GENERIC)
+
+
+@pytest.mark.parametrize("layer_size,stack_size", [(1, 1), (2, 1), (4, 1), (5, 2), (10, 2), (7, 3)])
+def test_pipelined_variants_with_partial_last_stage(layer_size, stack_size):
+    """Layer counts that do not fill the last stage (FOLD holds 3 layers per stage, PIPE 4): the
+    missing layers are packed as zeros and must act as the identity, and the head must add the
+    skip 1x1 of the REAL last layer exactly once.  Greedy runs of the pipelined variants equal
+    the generic kernel's; teacher-forced logits agree within the parity tolerance; what AUTO
+    picks is one of them."""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=layer_size, stack_size=stack_size, input_channels=256, residual_channels=64,
+               skip_channels=64)
+    sd = make_state_dict(**cfg, seed=3, gain=2.0, head_gain=6.0)
+    rf = sum(2 ** (l % layer_size) for l in range(layer_size * stack_size)) + 2
+    B, n_new = 3, 40
+    pidx = synthetic_indices(B, rf, 256, 21).to(DEV)
+    runs, logits, picks = {}, {}, {}
+    for variant in (N.GEN_GENERIC, N.GEN_PIPE, N.GEN_FOLD):
+        g = _gen(cfg, sd, B, rf + n_new, variant=variant)
+        assert g.variant == variant
+        g.prime(pidx)
+        g.advance(n_new)
+        g.check_errors()
+        runs[variant] = g.samples.clone()
+        g2 = _gen(cfg, sd, B, rf + n_new, variant=variant)
+        ch, lg = g2.teacher_forced(runs[N.GEN_GENERIC], logits_t0=rf)
+        g2.check_errors()
+        logits[variant], picks[variant] = lg.cpu().numpy(), ch[:, rf:].cpu().numpy()
+    ref = logits[N.GEN_GENERIC]
+    top2 = np.sort(ref, axis=2)[:, :, -2:]
+    clear = (top2[:, :, 1] - top2[:, :, 0]) > 4 * LOGIT_TOL * np.abs(ref).max()   # (B, n_new)
+    assert clear.mean() > 0.5
+    for variant in (N.GEN_PIPE, N.GEN_FOLD):
+        assert rel_err(logits[variant], ref) < LOGIT_TOL, variant
+        # same history => same pick wherever the winner is clear of the parity tolerance
+        same = picks[variant] == picks[N.GEN_GENERIC]
+        assert same[clear[:, :same.shape[1]]].all(), variant
+        # ... and the free runs are equal up to their first unclear step
+        eq = (runs[variant] == runs[N.GEN_GENERIC])[:, rf:].cpu().numpy()
+        for b in range(B):
+            bad = np.flatnonzero(~eq[b])
+            assert bad.size == 0 or not clear[b, bad[0]], (variant, b)
+    assert _gen(cfg, sd, B, rf + 1).variant == N.GEN_FOLD
