@@ -32,7 +32,25 @@ struct FusedBwdAArgs {
 
 constexpr int FB_C = 64;
 
-__global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, int chunks_per_b,
+static int fb_device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 256;
+  return cus;
+}
+// Chunks per sequence so that the launch is ONE round of `per_cu` workgroups per CU, a chunk
+// being a whole number of 64-step tiles (fixed 512-step chunks gave 416-512 workgroups whatever
+// the layer's length: the shorter late layers took as long as the first).
+static void fb_chunks(int nt, int batch, int per_cu, int *chunks, int *chunk_t) {
+  const int tiles = (nt + W2_T - 1) / W2_T;
+  const int want = std::max(1, per_cu * fb_device_cus() / std::max(batch, 1));
+  const int chunk_tiles = std::max(1, (tiles + want - 1) / want);
+  *chunks = (tiles + chunk_tiles - 1) / chunk_tiles;
+  *chunk_t = chunk_tiles * W2_T;
+}
+
+__global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, int chunks_per_b, int chunk_t,
                                                               float *__restrict__ bias_part,
                                                               float *__restrict__ part) {
   constexpr int C = FB_C, LD = W2_LD, TT = W2_T;
@@ -43,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
-  const int tb = (a.t_begin & ~3) + ch * W2_CHUNK, te = min(a.t_end, tb + W2_CHUNK);
+  const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const int skip_lo = max(a.t_begin, a.t_skip0);
   const bool has_dxo = a.dxo.p != nullptr;
 
@@ -228,10 +246,11 @@ static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int bat
                                  float *slab, size_t slab_floats, hipStream_t s) {
   const int nt = a.t_end - (a.t_begin & ~3);
   if (a.t_end <= a.t_begin || batch <= 0) return true;
-  const int chunks = (nt + W2_CHUNK - 1) / W2_CHUNK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch, 2, &chunks, &chunk_t);
   const size_t need = (size_t)chunks * batch * 128 * 64;
   if (!bias_scratch || !slab || need > slab_floats) return false;
-  hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, bias_scratch, slab);
+  hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, chunk_t, bias_scratch, slab);
   hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 64 / 32), dim3(256), 0, s, op, slab, chunks * batch, 128, 64);
   hipLaunchKernelGGL(bias_reduce_kernel<WgOp>, dim3(128), dim3(64), 0, s, op, bias_scratch, chunks * batch, 128);
   return true;
@@ -260,7 +279,7 @@ struct FusedBwdBArgs {
 
 constexpr int FBB_LDS_FLOATS = 3 * 128 * W2_LD;
 
-__global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, int chunks_per_b,
+__global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, int chunks_per_b, int chunk_t,
                                                               float *__restrict__ part) {
   constexpr int C = FB_C, LD = W2_LD, TT = W2_T;
   extern __shared__ __attribute__((aligned(16))) float fbb_lds[];
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
-  const int tb = (a.t_out0 & ~3) + ch * W2_CHUNK, te = min(a.t_end, tb + W2_CHUNK);
+  const int tb = (a.t_out0 & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const bool has_dxo = a.dxo.p != nullptr;
 
   // ---- dx: wave -> (tap half, 32 u x 32 c block); B operand W_tap[o][32 wc + li], o = 2 kk + lh
@@ -460,14 +479,15 @@ static int launch_bwd_dx_wgfg64(const FusedBwdBArgs &a, const WgOp &op, int batc
     *done = true;
     return MVN_OK;
   }
-  const int chunks = (nt + W2_CHUNK - 1) / W2_CHUNK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch, 1, &chunks, &chunk_t);
   const size_t need = (size_t)chunks * batch * 128 * 128;
   if (!slab || need > slab_floats) return MVN_OK;
   const void *fn = (const void *)bwd_dx_wgfg64_kernel;
   const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(bwd_dx_wgfg64)");
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_dx_wgfg64_kernel, dim3(chunks * batch), dim3(512), FBB_LDS_FLOATS * sizeof(float), s, a,
-                     chunks, slab);
+                     chunks, chunk_t, slab);
   hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 128 / 32), dim3(256), 0, s, op, slab, chunks * batch, 128, 128);
   *done = true;
   return MVN_OK;

@@ -28,6 +28,7 @@
 #include "gemm_family.h"
 #include "fused_layer.h"
 #include "fused_bwd.h"
+#include "fused_fwd.h"
 
 namespace mvn {
 
@@ -850,6 +851,27 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     }();
     // (the layer's weights are re-packed k-major into the z scratch, which this path never
     // touches otherwise: z stays in LDS)
+    // ... and its persistent successor (fused_fwd.h: weights in registers, 64-column tiles);
+    // MOVENET_HIP_NO_PERSISTENT_FORWARD=1 keeps the per-tile kernel (read per call: tests run both)
+    const bool no_persistent = [] {
+      const char *e = getenv("MOVENET_HIP_NO_PERSISTENT_FORWARD");
+      return e && e[0] == '1';
+    }();
+    if (C == FL_C && Kc == FL_C && !has_ctx && !f16 && !no_fused && !no_persistent) {
+      FusedFwdPArgs fp;
+      fp.t_begin = A + d; fp.t_end = T; fp.d = d; fp.t_skip0 = t_skip0; fp.t_base = g.t_base;
+      fp.first_layer = (l == 0);
+      fp.wf = p->filter_w[l]; fp.wg = p->gate_w[l]; fp.wr = p->residual_w[l]; fp.ws = p->skip_w[l];
+      fp.br = p->residual_b[l]; fp.bs = p->skip_b[l];
+      fp.xin = xin; fp.xout = xout; fp.skip = skipv;
+      if (l == g.L - 1) fp.xout.p = nullptr;  // the last residual output is never used
+      fp.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+      fp.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
+      const int rc2 = launch_fused_layer64p(fp, batch, s);
+      if (rc2) return rc2;
+      A += d;
+      continue;
+    }
     if (C == FL_C && Kc == FL_C && !has_ctx && !f16 && !no_fused && (size_t)g.act >= (size_t)g.L * FL_PACK_F) {
       if (l == 0)
         for (int ll = 0; ll < g.L; ++ll)
