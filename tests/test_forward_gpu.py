@@ -267,3 +267,36 @@ def test_fused_backward_kernels_match_two_kernel_forms_and_oracle(monkeypatch, l
                 assert g is None, k
             else:
                 assert rel_err(g, params[k].grad) < 3e-4, k
+
+
+@pytest.mark.parametrize("layers,t_len,batch", [((3, 2), 100, 3), ((10, 1), 1024 + 700 + 37, 2), ((6, 2), 64 * 9 + 1, 17)])
+def test_persistent_forward_kernel_matches_per_tile_kernel_and_oracle(monkeypatch, layers, t_len, batch):
+    """C = K = 64 takes the persistent forward layer kernel (csrc/fused_fwd.h); the per-tile
+    kernel (MOVENET_HIP_NO_PERSISTENT_FORWARD=1) sums each f/g value in one 128-deep chain where
+    this one adds two 64-deep halves: equal to fp32 rounding.  Ragged lengths put t_begin, RF - 1
+    and T inside tiles; batch 17 makes the one-round chunking uneven.  Inference (no tanh/sigmoid
+    saved) and training mode, logits and probabilities."""
+    from oracle import wavenet_oracle as O
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=layers[0], stack_size=layers[1], input_channels=256, residual_channels=64,
+               skip_channels=64)
+    sd = make_state_dict(**cfg, seed=6, gain=1.5)
+    dims = O.Dims(**cfg)
+    x = one_hot(synthetic_indices(batch, t_len, 256, 78), 256)
+
+    def outputs(per_tile, train):
+        if per_tile:
+            monkeypatch.setenv("MOVENET_HIP_NO_PERSISTENT_FORWARD", "1")
+        else:
+            monkeypatch.delenv("MOVENET_HIP_NO_PERSISTENT_FORWARD", raising=False)
+        m = _model(cfg, sd)
+        m.train(train)
+        with torch.set_grad_enabled(train):
+            return m(x.to(DEV), output_unnormalized=True).detach().cpu()
+
+    for train in (False, True):
+        a, b_ = outputs(False, train), outputs(True, train)
+        assert rel_err(a, b_) < 2e-6, train
+    if t_len <= 700 and batch <= 4:
+        want = O.forward(sd, dims, x, output_unnormalized=True)
+        assert rel_err(outputs(False, False), want) < LOGIT_TOL
