@@ -845,7 +845,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     };
     // C = K = 64, audio only, fp32: the layer as ONE kernel (fused_layer.h); same bits as the
     // two-kernel form below (MOVENET_HIP_NO_FUSED_FORWARD=1 keeps the latter: A/B and tests)
-    static const bool no_fused = [] {
+    const bool no_fused = [] {
       const char *e = getenv("MOVENET_HIP_NO_FUSED_FORWARD");
       return e && e[0] == '1';
     }();
