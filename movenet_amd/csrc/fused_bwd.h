@@ -42,12 +42,12 @@ static int fb_device_cus() {
 // Chunks per sequence so that the launch is ONE round of `per_cu` workgroups per CU, a chunk
 // being a whole number of 64-step tiles (fixed 512-step chunks gave 416-512 workgroups whatever
 // the layer's length: the shorter late layers took as long as the first).
-static void fb_chunks(int nt, int batch, int per_cu, int *chunks, int *chunk_t) {
-  const int tiles = (nt + W2_T - 1) / W2_T;
+static void fb_chunks(int nt, int batch, int per_cu, int *chunks, int *chunk_t, int tile = W2_T) {
+  const int tiles = (nt + tile - 1) / tile;
   const int want = std::max(1, per_cu * fb_device_cus() / std::max(batch, 1));
   const int chunk_tiles = std::max(1, (tiles + want - 1) / want);
   *chunks = (tiles + chunk_tiles - 1) / chunk_tiles;
-  *chunk_t = chunk_tiles * W2_T;
+  *chunk_t = chunk_tiles * tile;
 }
 
 __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, int chunks_per_b, int chunk_t,

@@ -18,6 +18,7 @@
 // Summation order differs from fused_layer64_kernel (two 64-deep partial sums instead of one
 // 128-deep chain): same values to fp32 rounding, not the same bits.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #include "gemm_family.h"
 #include "fused_bwd.h"
@@ -32,10 +33,13 @@ struct FusedFwdPArgs {
   Act xin, xout, th, sg, skip;   // xout.p == NULL: last layer; th/sg.p == NULL: nothing saved
 };
 
-constexpr int FP_LDS_FLOATS = (2 * 128 + 3 * 64) * W2_LD;
-
-__global__ __launch_bounds__(512, 1) void fused_layer64p_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
-  constexpr int C = 64, LD = W2_LD, TT = W2_T;
+// NTB = 32-step blocks per tile: 2 -> 64-column tiles, 512 threads, one workgroup per CU (122 KB of
+// LDS); 1 -> 32-column tiles, 256 threads, TWO workgroups per CU (65 KB each) whose phases run
+// under each other's MFMAs -- the same registers per wave either way (a wave's blocks are 32 wide).
+template <int NTB>
+__global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_kernel(FusedFwdPArgs a, int chunks_per_b,
+                                                                               int chunk_t) {
+  constexpr int C = 64, TT = 32 * NTB, LD = TT + 4, NTH = 256 * NTB;
   extern __shared__ __attribute__((aligned(16))) float fp_lds[];
   float (*X)[128][LD] = (float (*)[128][LD])fp_lds;              // [2]: x(t - d) rows | x(t) rows
   float (*Z)[LD] = (float (*)[LD])(fp_lds + 2 * 128 * LD);       // gated activation
@@ -51,40 +55,33 @@ __global__ __launch_bounds__(512, 1) void fused_layer64p_kernel(FusedFwdPArgs a,
   // ---- the weights reach their registers through LDS: a lane's values lie 512 (256) bytes apart
   // in the (out, in, tap) / (out, in) tensors -- fetched straight from global memory every wave
   // instruction touched 64 cache lines, 49 000 line requests per workgroup: longer than its tiles
-  {
-    float *wl = fp_lds;  // wf (8192) | wg (8192) | wr (4096) | ws (4096) floats = 96 KB of the 119
-    for (int i = tid; i < 2048; i += 512) {
-      *(f4 *)&wl[4 * i] = *(const f4 *)&a.wf[4 * i];
-      *(f4 *)&wl[8192 + 4 * i] = *(const f4 *)&a.wg[4 * i];
-    }
-    for (int i = tid; i < 1024; i += 512) {
-      *(f4 *)&wl[16384 + 4 * i] = *(const f4 *)&a.wr[4 * i];
-      *(f4 *)&wl[20480 + 4 * i] = *(const f4 *)&a.ws[4 * i];
-    }
-  }
-  __syncthreads();
-  // ---- first product: wave -> block (tt, cc) of f AND g over the 64 rows of tap kh
-  const int tt = (wave >> 1) & 1, cc = wave & 1, kh = wave >> 2;
-  float wfr[32], wgr[32];
+  // (three passes of 32 KB through the tile buffers: filter, gate, residual | skip)
+  const int tt = (wave >> 1) % NTB, cc = wave & 1, kh = wave / (2 * NTB);   // first product: block (tt, cc), tap kh
+  const int t2 = wave >> 2, mt = wave & 3;                                  // second product: block (t2, mt)
+  float wfr[32], wgr[32], wrs[32];
 #pragma unroll
-  for (int kk = 0; kk < 32; ++kk) {
-    const int o = ((32 * cc + li) * C + 2 * kk + lh) * 2 + kh;
-    wfr[kk] = fp_lds[o];
-    wgr[kk] = fp_lds[8192 + o];
-  }
-  // ---- second product: wave -> block (t2, mt) of [residual | skip]
-  const int t2 = wave >> 2, mt = wave & 3;
-  float wrs[32];
+  for (int pass = 0; pass < 3; ++pass) {
+    const float *src = pass == 0 ? a.wf : pass == 1 ? a.wg : a.wr;
+    for (int i = tid; i < (pass < 2 ? 2048 : 1024); i += NTH) *(f4 *)&fp_lds[4 * i] = *(const f4 *)&src[4 * i];
+    if (pass == 2)
+      for (int i = tid; i < 1024; i += NTH) *(f4 *)&fp_lds[4096 + 4 * i] = *(const f4 *)&a.ws[4 * i];
+    __syncthreads();
 #pragma unroll
-  for (int kk = 0; kk < 32; ++kk) {
-    const int c = 2 * kk + lh, m2 = 32 * (mt & 1) + li;
-    wrs[kk] = fp_lds[(mt < 2 ? 16384 : 20480) + m2 * C + c];
+    for (int kk = 0; kk < 32; ++kk) {
+      if (pass < 2) {
+        const float v = fp_lds[((32 * cc + li) * C + 2 * kk + lh) * 2 + kh];
+        if (pass == 0) wfr[kk] = v; else wgr[kk] = v;
+      } else {
+        wrs[kk] = fp_lds[(mt < 2 ? 0 : 4096) + (32 * (mt & 1) + li) * C + 2 * kk + lh];
+      }
+    }
+    __syncthreads();
   }
   const float bias2 = (mt < 2 ? a.br : a.bs)[32 * (mt & 1) + li];
-  __syncthreads();  // the weights are in registers: the buffers take their tiles
 
-  // ---- staging: thread -> rows (tid >> 4) + 32 p, columns 4 (tid & 15) .. +3
-  const int srow = tid >> 4, st = 4 * (tid & 15);
+  // ---- staging: thread -> rows (tid / TPR) + 32 p, columns 4 (tid % TPR) .. +3
+  constexpr int TPR = TT / 4;  // threads per row
+  const int srow = tid / TPR, st = 4 * (tid % TPR);
   f4 xreg[4], kreg[2];
   auto interior = [&](int t0) { return t0 >= a.t_begin && t0 + TT <= te; };
   auto gload_x = [&](int t0) {
@@ -175,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64p_kernel(FusedFwdPArgs a,
       }
     }
     // ---- the taps meet: this wave finishes t-groups q = 2 kh, 2 kh + 1 of its block and hands the
-    // other two to its partner (wave ^ 4) through the staging tiles
+    // other two to its partner (the same block, other tap) through the staging tiles
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
       const int q = 2 * (1 - kh) + qq, tc = 32 * tt + 8 * q + h4;
@@ -271,17 +268,24 @@ __global__ __launch_bounds__(512, 1) void fused_layer64p_kernel(FusedFwdPArgs a,
   }
 }
 
-static int launch_fused_layer64p(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+template <int NTB>
+static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+  constexpr int TT = 32 * NTB, LDS_BYTES = (2 * 128 + 3 * 64) * (TT + 4) * (int)sizeof(float);
   const int nt = a.t_end - (a.t_begin & ~3);
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
-  fb_chunks(nt, batch, 1, &chunks, &chunk_t);  // one workgroup per CU, one round (fused_bwd.h)
-  const void *fn = (const void *)fused_layer64p_kernel;
+  fb_chunks(nt, batch, NTB == 1 ? 2 : 1, &chunks, &chunk_t, TT);  // one round of workgroups (fused_bwd.h)
+  const void *fn = (const void *)fused_layer64p_kernel<NTB>;
   const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(fused_layer64p)");
   if (rc) return rc;
-  hipLaunchKernelGGL(fused_layer64p_kernel, dim3(chunks * batch), dim3(512), FP_LDS_FLOATS * sizeof(float), s, a, chunks,
-                     chunk_t);
+  hipLaunchKernelGGL(fused_layer64p_kernel<NTB>, dim3(chunks * batch), dim3(256 * NTB), LDS_BYTES, s, a, chunks, chunk_t);
   return MVN_OK;
+}
+// MOVENET_HIP_FORWARD_TILE=64: the one-workgroup-per-CU form (A/B)
+static int launch_fused_layer64p(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+  const char *e = getenv("MOVENET_HIP_FORWARD_TILE");
+  if (e && e[0] == '6') return launch_fused_layer64p_t<2>(a, batch, s);
+  return launch_fused_layer64p_t<1>(a, batch, s);
 }
 
 }  // namespace mvn
