@@ -19,6 +19,7 @@
 // 128-deep chain): same values to fp32 rounding, not the same bits.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "gemm_family.h"
 #include "fused_bwd.h"
@@ -173,27 +174,37 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
     }
     // ---- the taps meet: this wave finishes t-groups q = 2 kh, 2 kh + 1 of its block and hands the
     // other two to its partner (the same block, other tap) through the staging tiles
+    // (the t-group index is a compile-time constant on either side of the branch: indexed at run
+    // time the accumulator registers were moved through s_set_gpr_idx, 24 switches per tile)
+    auto hand_over = [&](auto QB) {
+      constexpr int q0 = decltype(QB)::value;
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const int q = 2 * (1 - kh) + qq, tc = 32 * tt + 8 * q + h4;
-      *(f4 *)&S1[32 * cc + li][tc] = f4{accf[4 * q], accf[4 * q + 1], accf[4 * q + 2], accf[4 * q + 3]};
-      *(f4 *)&S2[32 * cc + li][tc] = f4{accg[4 * q], accg[4 * q + 1], accg[4 * q + 2], accg[4 * q + 3]};
-    }
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = q0 + qq, tc = 32 * tt + 8 * q + h4;
+        *(f4 *)&S1[32 * cc + li][tc] = f4{accf[4 * q], accf[4 * q + 1], accf[4 * q + 2], accf[4 * q + 3]};
+        *(f4 *)&S2[32 * cc + li][tc] = f4{accg[4 * q], accg[4 * q + 1], accg[4 * q + 2], accg[4 * q + 3]};
+      }
+    };
+    if (kh == 0) hand_over(std::integral_constant<int, 2>()); else hand_over(std::integral_constant<int, 0>());
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above have had the MFMAs to land (cf. fused_bwd.h)
     __syncthreads();
+    auto finish = [&](auto QB) {
+      constexpr int q0 = decltype(QB)::value;
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const int q = 2 * kh + qq, tc = 32 * tt + 8 * q + h4;
-      const f4 pf = *(const f4 *)&S1[32 * cc + li][tc], pg = *(const f4 *)&S2[32 * cc + li][tc];
-      f4 tv, sv;
-      tv.x = tanh_fast(accf[4 * q] + pf.x);     sv.x = sigmoid_fast(accg[4 * q] + pg.x);
-      tv.y = tanh_fast(accf[4 * q + 1] + pf.y); sv.y = sigmoid_fast(accg[4 * q + 1] + pg.y);
-      tv.z = tanh_fast(accf[4 * q + 2] + pf.z); sv.z = sigmoid_fast(accg[4 * q + 2] + pg.z);
-      tv.w = tanh_fast(accf[4 * q + 3] + pf.w); sv.w = sigmoid_fast(accg[4 * q + 3] + pg.w);
-      *(f4 *)&Z[32 * cc + li][tc] = f4{tv.x * sv.x, tv.y * sv.y, tv.z * sv.z, tv.w * sv.w};
-      *(f4 *)&S1[32 * cc + li][tc] = tv;  // (the slots this lane has just read)
-      *(f4 *)&S2[32 * cc + li][tc] = sv;
-    }
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = q0 + qq, tc = 32 * tt + 8 * q + h4;
+        const f4 pf = *(const f4 *)&S1[32 * cc + li][tc], pg = *(const f4 *)&S2[32 * cc + li][tc];
+        f4 tv, sv;
+        tv.x = tanh_fast(accf[4 * q] + pf.x);     sv.x = sigmoid_fast(accg[4 * q] + pg.x);
+        tv.y = tanh_fast(accf[4 * q + 1] + pf.y); sv.y = sigmoid_fast(accg[4 * q + 1] + pg.y);
+        tv.z = tanh_fast(accf[4 * q + 2] + pf.z); sv.z = sigmoid_fast(accg[4 * q + 2] + pg.z);
+        tv.w = tanh_fast(accf[4 * q + 3] + pf.w); sv.w = sigmoid_fast(accg[4 * q + 3] + pg.w);
+        *(f4 *)&Z[32 * cc + li][tc] = f4{tv.x * sv.x, tv.y * sv.y, tv.z * sv.z, tv.w * sv.w};
+        *(f4 *)&S1[32 * cc + li][tc] = tv;  // (the slots this lane has just read)
+        *(f4 *)&S2[32 * cc + li][tc] = sv;
+      }
+    };
+    if (kh == 0) finish(std::integral_constant<int, 0>()); else finish(std::integral_constant<int, 2>());
     if (more) lstore_x(cur ^ 1);
     __syncthreads();
     // ---- tanh / sigmoid leave for the backward pass; residual | skip block of this wave
