@@ -348,7 +348,9 @@ __device__ __forceinline__ int choose_class(const float (&lg)[4], float temperat
   float p[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) p[k] = e[k] * rs;
-  const float m2 = wave_max_dpp(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
+  // max over p = rs exactly: the largest e is exp(0) = 1.0 (v_exp_f32 of 0 is exact), 1.0 * rs = rs,
+  // and rounding is monotone for the others (e <= 1)  -- one wave-wide max reduction less per step
+  const float m2 = rs;
 #pragma unroll
   for (int k = 0; k < 4; ++k) e[k] = __expf(p[k] - m2);
   const float s2sum = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
