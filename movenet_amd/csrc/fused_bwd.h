@@ -261,7 +261,7 @@ static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int bat
 //   dx[u]   = [u >= t_lo] (dxo[u] + W1^T dfg[u]) + [u + d < T] W0^T dfg[u + d]     (B4 of sequence.hip)
 //   dWf|dWg[o][c][tap 1] += dfg[o][t] x[c][t],   [tap 0] += dfg[o][t] x[c][t - d]
 // The two-kernel form (gemm_wx_staged_kernel<DxOp> beside wgrad2_kernel<WgFgOpT, 2>) reads dfg
-// three times (389 + 290 MB per layer).  Here a 512-thread workgroup (one per CU: 102 KB of
+// three times (389 + 290 MB per layer).  Here a 512-thread workgroup (one per CU: 136 KB of
 // LDS) stages dfg[t] (128 x 64), dfg[t + d] (128 x 64) and [x(t - d); x(t)] (128 x 64) once per
 // tile; waves 0-3 take the tap-1 half of dx (K = the 128 rows of dfg[t]), waves 4-7 the tap-0
 // half (dfg[t + d]), both in the transposed form of the first half with their 64 weights per
@@ -277,14 +277,16 @@ struct FusedBwdBArgs {
   Act dxo, dfg, xin, dxi;       // dxo.p == NULL: last layer
 };
 
-constexpr int FBB_LDS_FLOATS = 3 * 128 * W2_LD;
+constexpr int FBB_LDS_FLOATS = 4 * 128 * W2_LD;  // dfg[t], dfg[t + d], [x(t - d); x(t)], the two dx halves: 136 KB
 
 __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, int chunks_per_b, int chunk_t,
                                                               float *__restrict__ part) {
   constexpr int C = FB_C, LD = W2_LD, TT = W2_T;
   extern __shared__ __attribute__((aligned(16))) float fbb_lds[];
   float (*As)[LD] = (float (*)[LD])fbb_lds;                    // dfg[t]      (df rows | dg rows)
-  float (*A2)[LD] = (float (*)[LD])(fbb_lds + 128 * LD);       // dfg[t + d]; later the two dx halves
+  float (*A2)[LD] = (float (*)[LD])(fbb_lds + 128 * LD);       // dfg[t + d]
+  float (*St)[LD] = (float (*)[LD])(fbb_lds + 3 * 128 * LD);   // the two dx halves [2][64]: a buffer of their own,
+                                                               // so that a tile costs two barriers, not four
   float (*Xs)[LD] = (float (*)[LD])(fbb_lds + 2 * 128 * LD);   // x(t - d) rows | x(t) rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,12 +428,11 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores (see the first half)
-    __syncthreads();  // every wave has read the tiles: A2 becomes the two staging tiles [2][64][LD]
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      *(f4 *)&A2[64 * half + 32 * wc + li][32 * wt + 8 * q + h4] =
+      *(f4 *)&St[64 * half + 32 * wc + li][32 * wt + 8 * q + h4] =
           f4{accd[4 * q], accd[4 * q + 1], accd[4 * q + 2], accd[4 * q + 3]};
-    __syncthreads();
+    __syncthreads();  // the dx halves are staged AND every wave has read the operand tiles
     {
       // rows srow + 32 p (p < 2), columns t0 + st .. +3 inside [t_out0, te)
       const int t = t0 + st;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int row = 32 * p + srow;
-        const f4 v1 = *(const f4 *)&A2[row][st], v0 = *(const f4 *)&A2[64 + row][st], o = ocur[p];
+        const f4 v1 = *(const f4 *)&St[row][st], v0 = *(const f4 *)&St[64 + row][st], o = ocur[p];
         const f4 r = f4{(v1.x + v0.x) + o.x, (v1.y + v0.y) + o.y, (v1.z + v0.z) + o.z, (v1.w + v0.w) + o.w};
         float *q = base + (size_t)row * a.dxi.ld;
         if (t >= a.t_out0 && t + 3 < te) {
@@ -451,13 +452,12 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
         }
       }
     }
-    __syncthreads();
     if (more) {
       lstore();
       ocur[0] = oreg[0];
       ocur[1] = oreg[1];
-      __syncthreads();
     }
+    __syncthreads();  // the next tile is staged; the staging tile has been read
   }
   // ---- this workgroup's slab (wgrad2_kernel's format, 128 x 128)
 #pragma unroll
