@@ -279,6 +279,238 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// STRIP form: one WAVE owns a strip of 32 time columns and runs the whole layer on it without a
+// single barrier (r2b timing builds: the tile kernels above spend 45 % of their time with waves
+// waiting at barriers for a sibling whose SIMD is held by another wave's MFMA burst).
+//   * both weight matrices sit in LDS for the whole launch (96 KB, read-only), laid out per MFMA
+//     block and lane so that one ds_read_b128 feeds four MFMAs (A operand: lane -> output row);
+//   * the strip's input, [x(t-d); x(t)] for 32 columns, goes from global memory straight into 64
+//     registers per lane as the B operand (lane -> column); the k order pairs channel c (lane
+//     half 0) with c + 4 (lane half 1), c running over the channels with bit 2 clear -- which
+//     are exactly the channels a lane of that half holds in the ACCUMULATOR layout (rows
+//     (r & 3) + 8 (r >> 2) + 4 lh), so that
+//       - f and g of a channel meet in one lane: gate in registers, no exchange;
+//       - z, computed in accumulator order, IS the B operand of the second product;
+//       - the residual add finds x(t) of its channel in the lane's own input registers;
+//   * tanh, sigmoid, x' and the skip term leave as dword stores, 128 contiguous bytes per channel
+//     and lane half (a whole cache line); the skip accumulator's old values are fetched under
+//     the second product into the dead x(t-d) registers.
+// Per strip and wave: 384 MFMAs, 96 ds_read_b128, ~290 vector-memory instructions.  The two
+// waves of a SIMD are independent: one's loads and stores run under the other's MFMAs.
+// ----------------------------------------------------------------------------------------
+constexpr int FS_LDS_FLOATS = 16384 + 8192 + 128;  // first product | second product | br, bs
+
+__global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
+  constexpr int C = 64;
+  extern __shared__ __attribute__((aligned(16))) float fs_lds[];
+  float *W1 = fs_lds, *W2 = fs_lds + 16384, *BI = fs_lds + 16384 + 8192;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int skip_lo = max(a.t_begin, a.t_skip0);
+  // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4]
+  for (int i = tid; i < 16384; i += 512) {
+    const int e = i & 3, ln = (i >> 2) & 63, kk = 4 * ((i >> 8) & 15) + e, blk = i >> 12;
+    const int j = kk & 31, tap = kk >> 5;
+    const int kc = (j & 3) + 8 * (j >> 2) + 4 * (ln >> 5), cm = 32 * (blk & 1) + (ln & 31);
+    W1[i] = ((blk >> 1) ? a.wg : a.wf)[((size_t)cm * C + kc) * 2 + tap];
+  }
+  for (int i = tid; i < 8192; i += 512) {
+    const int e = i & 3, ln = (i >> 2) & 63, kk = 4 * ((i >> 8) & 7) + e, blk = i >> 11;
+    const int kc = (kk & 3) + 8 * (kk >> 2) + 4 * (ln >> 5), m2 = 32 * (blk & 1) + (ln & 31);
+    W2[i] = (blk < 2 ? a.wr : a.ws)[(size_t)m2 * C + kc];
+  }
+  if (tid < 128) BI[tid] = tid < 64 ? a.br[tid] : a.bs[tid - 64];
+  __syncthreads();
+  const unsigned w1a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)W1 + 16u * lane;
+  const unsigned w2a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)W2 + 16u * lane;
+  typedef float fsv4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) fsv4 lds_v4;
+  // channel of accumulator register r of block h in this lane: 32 h + (r & 3) + 8 (r >> 2) + 4 lh
+  const int cbase = 4 * lh;
+
+  // Every global access below is a raw BUFFER access: (a resource per tensor and sequence:
+  // four scalar registers) + (row * ld: one scalar offset) + (one of five per-lane byte offsets).
+  // Formed as 64-bit vector addresses the ~290 accesses of a strip spilled 443 registers; as
+  // scalar row pointers + vector offsets they still cost a 64-bit vector add each and spilled the
+  // scalar file (130 v_writelane / v_readlane per strip).
+  constexpr int RSRC = 0x00020000;  // raw buffer, 32-bit data format (gfx9)
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xin.p + (size_t)b * a.xin.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t thb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.th.p + (size_t)b * a.th.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t sgb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.sg.p + (size_t)b * a.sg.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
+  const bool save = a.th.p != nullptr, has_out = a.xout.p != nullptr;
+  int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld;
+  // (row offsets = row * ld are re-formed where they are used, behind a fence on ld: hoisted out of
+  // the strip loop the ~120 products filled the scalar file and were spilled to vector lanes)
+#define FS_FENCE(x) asm volatile("" : "+s"(x))
+
+  // x(t) of a strip (the tap-1 half of the input, 32 registers) is fetched one strip AHEAD, under
+  // the second product of the strip before; the first product consumes it first, which gives the
+  // x(t - d) half, requested at the top of the strip, 128 MFMAs to arrive.  (Without it the wave
+  // counters showed 51 % of the wave cycles waiting for memory: a wave that issues MFMAs back to
+  // back starves the other wave of its SIMD, so the two fall into step and wait together.)
+  auto column = [&](int t0_, bool &live_, int &tc_) {
+    const int t_ = t0_ + li;
+    live_ = t_ >= a.t_begin && t_ < te;
+    tc_ = live_ ? t_ : a.t_begin;  // (clamped: dead lanes read a valid column, zeroed afterwards)
+  };
+  float xb1[32];  // x(t) of the current strip: B operand of k-steps 32..63, residual input
+  {
+    bool lv;
+    int tcc;
+    column(tb + 32 * wave, lv, tcc);
+    const int o1 = 4 * (cbase * a.xin.ld + tcc);
+    FS_FENCE(xld4);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+      xb1[j] = lv ? v : 0.f;
+    }
+  }
+
+  for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
+    const int t = t0 + li;
+    bool live;
+    int tc;
+    column(t0, live, tc);
+    const bool skip_live = t >= skip_lo && t < te;
+    // per-lane byte offsets (channel part 4 lh of the row + the column)
+    const int ox0 = 4 * (cbase * a.xin.ld + tc - a.d);
+    const int oth = 4 * (cbase * a.th.ld + tc), oxo = 4 * (cbase * a.xout.ld + tc);
+    const int osk = 4 * (cbase * a.skip.ld + (skip_live ? t : skip_lo));
+    // ---- x(t - d) of channel kc(j) + 4 lh: B operand of k-steps 0..31; later the skip accumulator's old values
+    float xa0[32];
+    FS_FENCE(xld4);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+      xa0[j] = live ? v : 0.f;
+    }
+    // ---- f | g: four 32 x 32 blocks (f c<32, f c>=32, g c<32, g c>=32), K = 128, the x(t) half first
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int kq = 0; kq < 16; ++kq) {
+      const int k4 = kq < 8 ? 8 + kq : kq - 8;
+      fsv4 aw[4];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w1a + 4u * (unsigned)((blk * 16 + k4) * 256));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[blk][e], k4 >= 8 ? xb1[4 * (k4 - 8) + e] : xa0[4 * k4 + e],
+                                                          acc[blk], 0, 0, 0);
+    }
+    // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
+    float z[32];
+    FS_FENCE(thld4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float tv = tanh_fast(acc[h][r]), sv = sigmoid_fast(acc[2 + h][r]);
+        z[16 * h + r] = tv * sv;
+        if (save && live) {
+          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, 0);
+        }
+      }
+    // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's
+    // x(t), both under the MFMAs below
+    FS_FENCE(skld4);
+    if (!a.first_layer) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xa0[16 * h + r] = __uint_as_float(
+              __builtin_amdgcn_raw_buffer_load_b32(skb, osk, (32 * h + (r & 3) + 8 * (r >> 2)) * skld4, 0));
+    }
+    float xn1[32];
+    const bool more = t0 + 32 * 8 < te;
+    if (more) {
+      bool lv;
+      int tcc;
+      column(t0 + 32 * 8, lv, tcc);
+      const int o1 = 4 * (cbase * a.xin.ld + tcc);
+      FS_FENCE(xld4);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+        xn1[j] = lv ? v : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xn1[j] = 0.f;
+    }
+    // ---- residual | skip: four blocks (res c<32, res c>=32, skip k<32, skip k>=32), K = 64
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      fsv4 aw[4];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w2a + 4u * (unsigned)((blk * 8 + k4) * 256));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[blk][e], z[4 * k4 + e], acc[blk], 0, 0, 0);
+    }
+    // ---- x' = (y + br) + x(t): x(t) of this lane's channel is input register 32 + 16 h + r
+    FS_FENCE(xold4);
+    FS_FENCE(skld4);
+    if (has_out && live) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[h][r] + BI[c0 + cbase]) + xb1[16 * h + r]), xob, oxo,
+                                                c0 * xold4, 0);
+        }
+    }
+    // ---- skip (+)= y + bs, columns t - t_base, live from skip_lo
+    if (skip_live) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          const float v = acc[2 + h][r] + BI[64 + k0 + cbase];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a.first_layer ? v : xa0[16 * h + r] + v), skb, osk, k0 * skld4, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) xb1[j] = xn1[j];
+  }
+}
+
+static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+  const int nt = a.t_end - (a.t_begin & ~3);
+  if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);  // a chunk: whole rounds of the 8 waves' strips
+  const void *fn = (const void *)fused_layer64s_kernel;
+  const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(fused_layer64s)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fused_layer64s_kernel, dim3(chunks * batch), dim3(512), FS_LDS_FLOATS * sizeof(float), s, a, chunks,
+                     chunk_t);
+  return MVN_OK;
+}
+
 template <int NTB>
 static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_t s) {
   constexpr int TT = 32 * NTB, LDS_BYTES = (2 * 128 + 3 * 64) * (TT + 4) * (int)sizeof(float);
@@ -292,11 +524,12 @@ static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_
   hipLaunchKernelGGL(fused_layer64p_kernel<NTB>, dim3(chunks * batch), dim3(256 * NTB), LDS_BYTES, s, a, chunks, chunk_t);
   return MVN_OK;
 }
-// MOVENET_HIP_FORWARD_TILE=64: the one-workgroup-per-CU form (A/B)
+// The strip kernel is the default; MOVENET_HIP_FORWARD_TILE=32 / 64 select the tile kernels (A/B, tests)
 static int launch_fused_layer64p(const FusedFwdPArgs &a, int batch, hipStream_t s) {
   const char *e = getenv("MOVENET_HIP_FORWARD_TILE");
   if (e && e[0] == '6') return launch_fused_layer64p_t<2>(a, batch, s);
-  return launch_fused_layer64p_t<1>(a, batch, s);
+  if (e && e[0] == '3') return launch_fused_layer64p_t<1>(a, batch, s);
+  return launch_fused_layer64s(a, batch, s);
 }
 
 }  // namespace mvn

@@ -297,6 +297,11 @@ def test_persistent_forward_kernel_matches_per_tile_kernel_and_oracle(monkeypatc
     for train in (False, True):
         a, b_ = outputs(False, train), outputs(True, train)
         assert rel_err(a, b_) < 2e-6, train
+        # the strip kernel is the default; its tile-kernel siblings (32 / 64 columns) must agree too
+        for tile in ("32", "64"):
+            monkeypatch.setenv("MOVENET_HIP_FORWARD_TILE", tile)
+            assert rel_err(outputs(False, train), b_) < 2e-6, (train, tile)
+        monkeypatch.delenv("MOVENET_HIP_FORWARD_TILE")
     if t_len <= 700 and batch <= 4:
         want = O.forward(sd, dims, x, output_unnormalized=True)
         assert rel_err(outputs(False, False), want) < LOGIT_TOL
