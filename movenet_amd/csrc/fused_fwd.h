@@ -311,17 +311,21 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const int li = lane & 31, lh = lane >> 5;
   const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const int skip_lo = max(a.t_begin, a.t_skip0);
-  // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4]
-  for (int i = tid; i < 16384; i += 512) {
-    const int e = i & 3, ln = (i >> 2) & 63, kk = 4 * ((i >> 8) & 15) + e, blk = i >> 12;
-    const int j = kk & 31, tap = kk >> 5;
-    const int kc = (j & 3) + 8 * (j >> 2) + 4 * (ln >> 5), cm = 32 * (blk & 1) + (ln & 31);
-    W1[i] = ((blk >> 1) ? a.wg : a.wf)[((size_t)cm * C + kc) * 2 + tap];
+  // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4].  The loop runs over the SOURCE
+  // elements (coalesced reads of the (out, in, tap) / (out, in) tensors) and scatters into LDS.
+  for (int sI = tid; sI < 2 * 8192; sI += 512) {
+    const int g = sI >> 13, r = sI & 8191;        // g: 0 filter, 1 gate
+    const int tap = r & 1, kc = (r >> 1) & 63, cm = r >> 7;
+    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3), kk = j + 32 * tap;
+    const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
+    W1[((blk * 16 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? a.wg : a.wf)[r];
   }
-  for (int i = tid; i < 8192; i += 512) {
-    const int e = i & 3, ln = (i >> 2) & 63, kk = 4 * ((i >> 8) & 7) + e, blk = i >> 11;
-    const int kc = (kk & 3) + 8 * (kk >> 2) + 4 * (ln >> 5), m2 = 32 * (blk & 1) + (ln & 31);
-    W2[i] = (blk < 2 ? a.wr : a.ws)[(size_t)m2 * C + kc];
+  for (int sI = tid; sI < 2 * 4096; sI += 512) {
+    const int g = sI >> 12, r = sI & 4095;        // g: 0 residual, 1 skip
+    const int kc = r & 63, m2 = r >> 6;
+    const int lhs = (kc >> 2) & 1, kk = (kc & 3) + 4 * (kc >> 3);
+    const int blk = 2 * g + (m2 >> 5), ln = (m2 & 31) + 32 * lhs;
+    W2[((blk * 8 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? a.ws : a.wr)[r];
   }
   if (tid < 128) BI[tid] = tid < 64 ? a.br[tid] : a.bs[tid - 64];
   __syncthreads();
