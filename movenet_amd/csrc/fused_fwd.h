@@ -533,6 +533,9 @@ static int launch_fused_layer64p(const FusedFwdPArgs &a, int batch, hipStream_t 
   const char *e = getenv("MOVENET_HIP_FORWARD_TILE");
   if (e && e[0] == '6') return launch_fused_layer64p_t<2>(a, batch, s);
   if (e && e[0] == '3') return launch_fused_layer64p_t<1>(a, batch, s);
+  // (the strip kernel's buffer resources span 2 GB from a sequence's base: rows of more than 4 M
+  // columns -- 25 x the reference's MAX_AUDIO_FRAMES -- go to the tile kernel)
+  if (a.xin.ld > (1 << 22) || a.skip.ld > (1 << 22)) return launch_fused_layer64p_t<1>(a, batch, s);
   return launch_fused_layer64s(a, batch, s);
 }
 
