@@ -1091,7 +1091,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     const char *e = getenv("MOVENET_HIP_NO_FUSED_BACKWARD");
     return !(e && e[0] == '1');
   }();
-  const bool fork = bias_scratch2 && !no_side;
+  // (with both fused halves every kernel of the layer loop runs on the caller's stream: no fork,
+  // and none of the two event records + waits per layer that go with it -- ~60 gaps of ~8 us per step)
+  const bool all_fused = fused_bwd && C == 64 && Kc == 64 && !has_ctx;
+  const bool fork = bias_scratch2 && !no_side && !all_fused;
   hipStream_t s2 = s;
   if (fork) {
     rc = side_stream(&side);
