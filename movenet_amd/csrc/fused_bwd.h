@@ -238,6 +238,39 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
   }
 }
 
+// The first half's two reductions in ONE launch (slab_reduce_kernel's scheme: 32 elements x 8 slab
+// segments per workgroup, fixed order): workgroups [0, 256) take the 128 x 64 weight-gradient
+// elements, [256, 260) the 128 bias sums.
+template <class Op>
+__global__ __launch_bounds__(256) void reduce_rs64_kernel(Op op, const float *__restrict__ part,
+                                                          const float *__restrict__ bias_part, int nparts) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const bool is_bias = blockIdx.x >= 256;
+  const size_t stride = is_bias ? 128 : (size_t)128 * 64;
+  const size_t idx = is_bias ? (size_t)(blockIdx.x - 256) * 32 + e : (size_t)blockIdx.x * 32 + e;
+  const float *src = is_bias ? bias_part : part;
+  const int per = (nparts + 7) / 8, p0 = seg * per, p1 = min(nparts, p0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = p0;
+  for (; q + 3 < p1; q += 4) {
+    s0 += src[(size_t)q * stride + idx];
+    s1 += src[(size_t)(q + 1) * stride + idx];
+    s2 += src[(size_t)(q + 2) * stride + idx];
+    s3 += src[(size_t)(q + 3) * stride + idx];
+  }
+  for (; q < p1; ++q) s0 += src[(size_t)q * stride + idx];
+  red[seg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (seg == 0) {
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][e];
+    float *dst = is_bias ? op.db((int)idx) : op.dw((int)(idx >> 6), (int)(idx & 63));
+    if (dst) *dst += t;
+  }
+}
+
 // `op` describes where the gradients go (WgRsOp::dw / db); slab: chunks * batch * 128 * 64 floats,
 // bias_scratch: chunks * batch * 128 floats.  False when the scratch is too small (the caller
 // then runs the two-kernel form).
@@ -251,8 +284,7 @@ static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int bat
   const size_t need = (size_t)chunks * batch * 128 * 64;
   if (!bias_scratch || !slab || need > slab_floats) return false;
   hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, chunk_t, bias_scratch, slab);
-  hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 64 / 32), dim3(256), 0, s, op, slab, chunks * batch, 128, 64);
-  hipLaunchKernelGGL(bias_reduce_kernel<WgOp>, dim3(128), dim3(64), 0, s, op, bias_scratch, chunks * batch, 128);
+  hipLaunchKernelGGL(reduce_rs64_kernel<WgOp>, dim3(256 + 4), dim3(256), 0, s, op, slab, bias_scratch, chunks * batch);
   return true;
 }
 
