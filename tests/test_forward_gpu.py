@@ -305,3 +305,28 @@ def test_persistent_forward_kernel_matches_per_tile_kernel_and_oracle(monkeypatc
     if t_len <= 700 and batch <= 4:
         want = O.forward(sd, dims, x, output_unnormalized=True)
         assert rel_err(outputs(False, False), want) < LOGIT_TOL
+
+
+@pytest.mark.parametrize("t_len", [64, 63, 1000])
+def test_onehot_to_index_kernels(t_len):
+    """mvn_onehot_to_index: class index per column, -1 where a column is not exactly one-hot
+    (two ones, a value that is neither 0 nor 1, no one at all).  T % 4 == 0 takes the float4
+    kernel, otherwise the scalar one."""
+    from movenet_amd import _native as N
+    B, Q = 3, 256
+    idx = synthetic_indices(B, t_len, Q, 5)
+    x = one_hot(idx, Q)
+    want = idx.clone().to(torch.int32)
+    x[0, 7, 3] = 1.0
+    want[0, 3] = -1 if idx[0, 3] != 7 else want[0, 3]       # a second one
+    x[1, int(idx[1, 5]), 5] = 0.5
+    want[1, 5] = -1                                          # neither 0 nor 1
+    x[2, int(idx[2, t_len - 1]), t_len - 1] = 0.0
+    want[2, t_len - 1] = -1                                  # no one at all
+    x[2, (int(idx[2, 0]) + 1) % Q, 0] = 1e-30
+    want[2, 0] = -1                                          # a stray tiny value
+    xd = x.to(DEV).contiguous()
+    got = torch.empty((B, t_len), dtype=torch.int32, device=DEV)
+    N.check(N.lib().mvn_onehot_to_index(xd.data_ptr(), got.data_ptr(), B, Q, t_len, None), "mvn_onehot_to_index")
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
