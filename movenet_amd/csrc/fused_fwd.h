@@ -515,6 +515,114 @@ static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t 
   return MVN_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// The strip form for the head's 1x1 convs with 64 x 256 weights (conv1 forward: 64 -> 256 rows,
+// leaky-ReLU in and out; its data gradient: 256 -> 64 rows through W^T, times the leaky-ReLU
+// derivative): the generic kernel reads a 64-row input once per 64-row OUTPUT block (conv1: four
+// times) and ran at 1.5 TB/s.  Same recipe as fused_layer64s_kernel: weights in LDS (64 KB), the
+// strip's input in registers as the B operand, raw buffer accesses, no barrier.
+//   IN: 0 identity, 1 leaky-ReLU on load;  OUT: 1 leaky(y + bias), 2 y * leaky'(ref)
+// ----------------------------------------------------------------------------------------
+struct DenseStripArgs {
+  int t_begin, t_end, t_out_end;
+  const float *wmat;  // W[m][k] = TRANSPOSED ? wmat[k * M + m] : wmat[m * K + k]
+  const float *bias;
+  Act xin, yout, ref;
+};
+
+template <int K, int M, int IN, int OUT, bool TRANSPOSED>
+__global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, int chunks_per_b, int chunk_t) {
+  static_assert(K * M == 16384 && K % 8 == 0 && M % 32 == 0, "64 KB of weights");
+  constexpr int NB = M / 32, NK4 = K / 8;
+  extern __shared__ __attribute__((aligned(16))) float ds_lds[];
+  float *W = ds_lds, *BI = ds_lds + 16384;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  for (int r = tid; r < 16384; r += 512) {  // source order: coalesced
+    const int m = TRANSPOSED ? r % M : r / K, k = TRANSPOSED ? r / M : r % K;
+    const int kk = k >> 1;
+    W[(((m >> 5) * NK4 + (kk >> 2)) * 64 + (m & 31) + 32 * (k & 1)) * 4 + (kk & 3)] = a.wmat[r];
+  }
+  if (OUT == 1 && tid < M) BI[tid] = a.bias[tid];
+  __syncthreads();
+  const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)W + 16u * lane;
+  typedef float dsv4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) dsv4 lds_v4;
+  constexpr int RSRC = 0x00020000;
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xin.p + (size_t)b * a.xin.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.yout.p + (size_t)b * a.yout.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ref.p + (size_t)b * a.ref.sb), 0, 0x7FFFFFFF, RSRC);
+  int xld4 = 4 * a.xin.ld, yld4 = 4 * a.yout.ld, rld4 = 4 * a.ref.ld;
+  for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
+    const int t = t0 + li;
+    const bool live = t >= a.t_begin && t < te, out_live = live && t < a.t_out_end;
+    const int tc = live ? t : a.t_begin;
+    const int ox = 4 * (lh * a.xin.ld + tc), oy = 4 * (4 * lh * a.yout.ld + tc), orf = 4 * (4 * lh * a.ref.ld + tc);
+    float xr[K / 2];
+    FS_FENCE(xld4);
+#pragma unroll
+    for (int kk = 0; kk < K / 2; ++kk) {
+      float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox, 2 * kk * xld4, 0));
+      if (IN == 1) v = leaky(v);
+      xr[kk] = live ? v : 0.f;
+    }
+    // (all of the strip's loads are issued before its first MFMA: the scheduler otherwise requests
+    // the K = 256 input just in time, 65 registers and a memory round trip every few MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < NK4; ++k4) {
+      dsv4 aw[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(wa + 4u * (unsigned)((blk * NK4 + k4) * 256));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[blk][e], xr[4 * k4 + e], acc[blk], 0, 0, 0);
+    }
+    FS_FENCE(yld4);
+    FS_FENCE(rld4);
+    if (out_live) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m0 = 32 * blk + (r & 3) + 8 * (r >> 2);
+          float y = acc[blk][r];
+          if (OUT == 1) {
+            y = leaky(y + BI[m0 + 4 * lh]);
+          } else {
+            const float rv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, orf, m0 * rld4, 0));
+            y = y * (rv > 0.f ? 1.0f : kLeakySlope);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), yb, oy, m0 * yld4, 0);
+        }
+    }
+  }
+}
+
+template <int K, int M, int IN, int OUT, bool TRANSPOSED>
+static int launch_dense_strip(const DenseStripArgs &a, int batch, hipStream_t s) {
+  const int nt = a.t_end - (a.t_begin & ~3);
+  if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);
+  const void *fn = (const void *)dense_strip_kernel<K, M, IN, OUT, TRANSPOSED>;
+  const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(dense_strip)");
+  if (rc) return rc;
+  hipLaunchKernelGGL((dense_strip_kernel<K, M, IN, OUT, TRANSPOSED>), dim3(chunks * batch), dim3(512),
+                     (16384 + 256) * sizeof(float), s, a, chunks, chunk_t);
+  return MVN_OK;
+}
+
 template <int NTB>
 static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_t s) {
   constexpr int TT = 32 * NTB, LDS_BYTES = (2 * 128 + 3 * 64) * (TT + 4) * (int)sizeof(float);

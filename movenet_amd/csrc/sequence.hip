@@ -907,7 +907,20 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     h1.K = Kc; h1.t_begin = g.pad; h1.t_end = g.pad + g.S; h1.M = Q; h1.wmat = p->head1_w;
     h1.ldw = Kc; h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v;
     h1.t_out_end = g.pad + g.S; h1.aligned_out = 1;
-    launch_gemm_staged(h1, Q, batch, s, f16);
+    // Q = 256, K = 64: the strip form reads the skip sum once (fused_fwd.h); MOVENET_HIP_NO_DENSE_STRIP=1: A/B
+    const bool strip = Q == 256 && Kc == 64 && !f16 && [] {
+      const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
+      return !(e && e[0] == '1');
+    }();
+    if (strip) {
+      DenseStripArgs da;
+      da.t_begin = g.pad; da.t_end = g.pad + g.S; da.t_out_end = g.pad + g.S;
+      da.wmat = p->head1_w; da.bias = p->head1_b; da.xin = skipv; da.yout = a1v; da.ref = a1v;
+      const int rc2 = launch_dense_strip<64, 256, IN_LRELU, OUT_BIAS_LRELU, false>(da, batch, s);
+      if (rc2) return rc2;
+    } else {
+      launch_gemm_staged(h1, Q, batch, s, f16);
+    }
   }
   if (S_out > 0) {
     DenseOp<IN_ID, OUT_BIAS, false> h2;
@@ -1042,6 +1055,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     d1.K = Q; d1.t_begin = g.pad; d1.t_end = g.pad + g.S; d1.M = Kc; d1.wmat = p->head1_w; d1.ldw = Kc;
     d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.pad + g.S;
     d1.aligned_out = 1;
+    // (conv1's data gradient has ONE 64-row output block: the generic kernel already reads da1 once,
+    // and the strip form measured 143 us against its 113)
     launch_gemm_staged(d1, Kc, batch, s);
   }
   // layers, last to first
