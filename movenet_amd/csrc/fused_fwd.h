@@ -525,36 +525,44 @@ static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t 
 // ----------------------------------------------------------------------------------------
 struct DenseStripArgs {
   int t_begin, t_end, t_out_end;
-  const float *wmat;  // W[m][k] = TRANSPOSED ? wmat[k * M + m] : wmat[m * K + k]
+  const float *wmat;  // W[m][k] = TRANSPOSED ? wmat[k * ldw + m] : wmat[m * ldw + k]
+  int ldw;
   const float *bias;
   Act xin, yout, ref;
 };
 
+// M = output rows per workgroup (blockIdx.y selects the row block): 64 x 256 weights for conv1
+// (one block of 256 rows), 256 x 128 for conv2 and its data gradient (two blocks: the input is
+// read twice instead of four times, 128 of its 256 rows' weights = 128 KB in LDS).
 template <int K, int M, int IN, int OUT, bool TRANSPOSED>
 __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, int chunks_per_b, int chunk_t) {
-  static_assert(K * M == 16384 && K % 8 == 0 && M % 32 == 0, "64 KB of weights");
+  static_assert(K * M <= 32768 && K % 8 == 0 && M % 32 == 0, "at most 128 KB of weights");
   constexpr int NB = M / 32, NK4 = K / 8;
   extern __shared__ __attribute__((aligned(16))) float ds_lds[];
-  float *W = ds_lds, *BI = ds_lds + 16384;
+  float *W = ds_lds, *BI = ds_lds + K * M;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int m_base = blockIdx.y * M;
   const int li = lane & 31, lh = lane >> 5;
   const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
-  for (int r = tid; r < 16384; r += 512) {  // source order: coalesced
+  for (int r = tid; r < K * M; r += 512) {  // source order: coalesced
     const int m = TRANSPOSED ? r % M : r / K, k = TRANSPOSED ? r / M : r % K;
     const int kk = k >> 1;
-    W[(((m >> 5) * NK4 + (kk >> 2)) * 64 + (m & 31) + 32 * (k & 1)) * 4 + (kk & 3)] = a.wmat[r];
+    const float v = TRANSPOSED ? a.wmat[(size_t)k * a.ldw + m_base + m] : a.wmat[(size_t)(m_base + m) * a.ldw + k];
+    W[(((m >> 5) * NK4 + (kk >> 2)) * 64 + (m & 31) + 32 * (k & 1)) * 4 + (kk & 3)] = v;
   }
-  if (OUT == 1 && tid < M) BI[tid] = a.bias[tid];
+  if (OUT != 2 && tid < M) BI[tid] = a.bias[m_base + tid];
   __syncthreads();
   const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)W + 16u * lane;
   typedef float dsv4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) dsv4 lds_v4;
   constexpr int RSRC = 0x00020000;
   const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xin.p + (size_t)b * a.xin.sb), 0, 0x7FFFFFFF, RSRC);
-  const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.yout.p + (size_t)b * a.yout.sb), 0, 0x7FFFFFFF, RSRC);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ref.p + (size_t)b * a.ref.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.yout.p + (size_t)b * a.yout.sb + (size_t)m_base * a.yout.ld), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.ref.p + (size_t)b * a.ref.sb + (size_t)m_base * a.ref.ld), 0, 0x7FFFFFFF, RSRC);
   int xld4 = 4 * a.xin.ld, yld4 = 4 * a.yout.ld, rld4 = 4 * a.ref.ld;
   for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
     const int t = t0 + li;
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
       xr[kk] = live ? v : 0.f;
     }
     // (all of the strip's loads are issued before its first MFMA: the scheduler otherwise requests
-    // the K = 256 input just in time, 65 registers and a memory round trip every few MFMAs)
+    // a K = 256 input just in time, 65 registers and a memory round trip every few MFMAs)
     __builtin_amdgcn_sched_barrier(0);
     f32x16 acc[NB];
 #pragma unroll
@@ -597,7 +605,9 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
         for (int r = 0; r < 16; ++r) {
           const int m0 = 32 * blk + (r & 3) + 8 * (r >> 2);
           float y = acc[blk][r];
-          if (OUT == 1) {
+          if (OUT == 0) {
+            y = y + BI[m0 + 4 * lh];
+          } else if (OUT == 1) {
             y = leaky(y + BI[m0 + 4 * lh]);
           } else {
             const float rv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, orf, m0 * rld4, 0));
@@ -609,17 +619,18 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
   }
 }
 
+// `m_total` output rows = m_total / M row blocks
 template <int K, int M, int IN, int OUT, bool TRANSPOSED>
-static int launch_dense_strip(const DenseStripArgs &a, int batch, hipStream_t s) {
+static int launch_dense_strip(const DenseStripArgs &a, int m_total, int batch, hipStream_t s) {
   const int nt = a.t_end - (a.t_begin & ~3);
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
-  fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);
+  fb_chunks(nt, batch * (m_total / M), 1, &chunks, &chunk_t, 256);
   const void *fn = (const void *)dense_strip_kernel<K, M, IN, OUT, TRANSPOSED>;
   const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(dense_strip)");
   if (rc) return rc;
-  hipLaunchKernelGGL((dense_strip_kernel<K, M, IN, OUT, TRANSPOSED>), dim3(chunks * batch), dim3(512),
-                     (16384 + 256) * sizeof(float), s, a, chunks, chunk_t);
+  hipLaunchKernelGGL((dense_strip_kernel<K, M, IN, OUT, TRANSPOSED>), dim3(chunks * batch, m_total / M), dim3(512),
+                     (K * M + M) * sizeof(float), s, a, chunks, chunk_t);
   return MVN_OK;
 }
 

@@ -915,8 +915,8 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     if (strip) {
       DenseStripArgs da;
       da.t_begin = g.pad; da.t_end = g.pad + g.S; da.t_out_end = g.pad + g.S;
-      da.wmat = p->head1_w; da.bias = p->head1_b; da.xin = skipv; da.yout = a1v; da.ref = a1v;
-      const int rc2 = launch_dense_strip<64, 256, IN_LRELU, OUT_BIAS_LRELU, false>(da, batch, s);
+      da.wmat = p->head1_w; da.ldw = Kc; da.bias = p->head1_b; da.xin = skipv; da.yout = a1v; da.ref = a1v;
+      const int rc2 = launch_dense_strip<64, 256, IN_LRELU, OUT_BIAS_LRELU, false>(da, Q, batch, s);
       if (rc2) return rc2;
     } else {
       launch_gemm_staged(h1, Q, batch, s, f16);
@@ -929,7 +929,20 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     // `out` is the caller's contiguous (B, Q, S_out): column s of the head = out column s - pad
     h2.yout = act_view(out - g.pad, batch, Q, S_out);
     h2.t_out_end = g.pad + S_out; h2.aligned_out = 0;
-    launch_gemm_staged(h2, Q, batch, s, f16);
+    const bool strip2 = Q == 256 && !f16 && [] {
+      const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
+      return !(e && e[0] == '1');
+    }();
+    if (strip2) {
+      // two row blocks of 128: a1 is read twice instead of once per 64-row block (four times)
+      DenseStripArgs da;
+      da.t_begin = h2.t_begin; da.t_end = h2.t_end; da.t_out_end = h2.t_out_end;
+      da.wmat = p->head2_w; da.ldw = Q; da.bias = p->head2_b; da.xin = a1v; da.yout = h2.yout; da.ref = a1v;
+      const int rc2 = launch_dense_strip<256, 128, IN_ID, OUT_BIAS, false>(da, Q, batch, s);
+      if (rc2) return rc2;
+    } else {
+      launch_gemm_staged(h2, Q, batch, s, f16);
+    }
     if (normalize) {
       if (Q <= 4 * CQ)
         hipLaunchKernelGGL(softmax_cols_kernel, dim3((S_out + 63) / 64, batch), dim3(256), 0, s, out, Q,
@@ -1041,6 +1054,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     d2.K = Q; d2.t_begin = g.pad; d2.t_end = g.pad + g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
     d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.pad + g.S;
     d2.aligned_out = 1;
+    // (the strip form measured 454 us here against 342: its 64 leaky-ReLU reference loads per strip
+    // come after the MFMAs, and there is no register left to fetch them ahead)
     launch_gemm_staged(d2, Q, batch, s);
   }
   {  // head conv1
