@@ -164,7 +164,7 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
     }
 
 
-def train_leg(dev, world, rank, steps=6, warmup=3, batch=16, t_len=16000):
+def train_leg(dev, world, rank, steps=6, warmup=5, batch=16, t_len=16000):
     import torch.distributed as dist
     """Secondary metric M2 (BASELINE.json): train-step tokens/sec on config 2 --
     forward (probabilities), cross_entropy on them (Q2), backward through the HIP
