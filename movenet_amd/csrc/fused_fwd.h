@@ -393,7 +393,12 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
-      xa0[j] = live ? v : 0.f;
+      xa0[j] = v;
+    }
+    // (interior strips -- wave-uniform test -- need no masking: 32 selects less per strip)
+    if (!(t0 >= a.t_begin && t0 + 32 <= te)) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xa0[j] = live ? xa0[j] : 0.f;
     }
     // ---- f | g: four 32 x 32 blocks (f c<32, f c>=32, g c<32, g c>=32), K = 128, the x(t) half first
     f32x16 acc[4];
@@ -451,7 +456,11 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
         const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
-        xn1[j] = lv ? v : 0.f;
+        xn1[j] = v;
+      }
+      if (!(t0 + 32 * 8 >= a.t_begin && t0 + 32 * 8 + 32 <= te)) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xn1[j] = lv ? xn1[j] : 0.f;
       }
     } else {
 #pragma unroll
