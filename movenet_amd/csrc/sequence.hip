@@ -1156,9 +1156,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
     bool fused_a = false;
-    if (fused_bwd && C == 64 && Kc == 64 && !has_ctx && bias_scratch2) {
+    if (fused_bwd && C == 64 && Kc == 64 && bias_scratch2) {
       // dz and the residual/skip weight gradients from ONE pass over dxo, dskip, tanh, sigmoid
-      // (fused_bwd.h); on the main stream: the side stream only keeps the filter/gate gradient
+      // (fused_bwd.h; conditioned layers too: nothing here touches the context); on the main
+      // stream: the side stream only keeps the filter/gate gradient
       FusedBwdAArgs fa;
       fa.t_begin = t_lo; fa.t_end = T; fa.t_skip0 = t_skip0; fa.t_base = g.t_base;
       fa.wr = p->residual_w[l]; fa.ws = p->skip_w[l];
