@@ -32,6 +32,9 @@ struct FusedFwdPArgs {
   const float *wr, *ws;          // (64 out, 64 in)
   const float *br, *bs;          // (64)
   Act xin, xout, th, sg, skip;   // xout.p == NULL: last layer; th/sg.p == NULL: nothing saved
+  // conditioned layers (strip kernel only): f,g += Wc ctx(t) + bc   (modules.py:58-63, :75-77)
+  const float *wcf = nullptr, *wcg = nullptr, *bcf = nullptr, *bcg = nullptr;  // (64, 64), (64)
+  Act ctx = Act{nullptr, 0, 0};
 };
 
 // NTB = 32-step blocks per tile: 2 -> 64-column tiles, 512 threads, one workgroup per CU (122 KB of
@@ -299,12 +302,13 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
 // Per strip and wave: 384 MFMAs, 96 ds_read_b128, ~290 vector-memory instructions.  The two
 // waves of a SIMD are independent: one's loads and stores run under the other's MFMAs.
 // ----------------------------------------------------------------------------------------
-constexpr int FS_LDS_FLOATS = 16384 + 8192 + 128;  // first product | second product | br, bs
-
+// HAS_CTX: the conditioned layer -- the context is a third K block of the first product (96 KB of
+// f|g weights), its 32 registers are the ones the unconditioned kernel uses to fetch x(t) a strip ahead.
+template <bool HAS_CTX>
 __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
-  constexpr int C = 64;
+  constexpr int C = 64, NK1 = HAS_CTX ? 24 : 16, W1_F = 4 * NK1 * 256;
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
-  float *W1 = fs_lds, *W2 = fs_lds + 16384, *BI = fs_lds + 16384 + 8192;
+  float *W1 = fs_lds, *W2 = fs_lds + W1_F, *BI = fs_lds + W1_F + 8192;  // BI: br | bs | bcf | bcg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
@@ -318,7 +322,17 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     const int tap = r & 1, kc = (r >> 1) & 63, cm = r >> 7;
     const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3), kk = j + 32 * tap;
     const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
-    W1[((blk * 16 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? a.wg : a.wf)[r];
+    W1[((blk * NK1 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? a.wg : a.wf)[r];
+  }
+  if (HAS_CTX) {
+    for (int sI = tid; sI < 2 * 4096; sI += 512) {
+      const int g = sI >> 12, r = sI & 4095;      // g: 0 filter, 1 gate context conv
+      const int kc = r & 63, cm = r >> 6;
+      const int lhs = (kc >> 2) & 1, kk = 64 + (kc & 3) + 4 * (kc >> 3);
+      const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
+      W1[((blk * NK1 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? a.wcg : a.wcf)[r];
+    }
+    if (tid < 128) BI[128 + tid] = tid < 64 ? a.bcf[tid] : a.bcg[tid - 64];
   }
   for (int sI = tid; sI < 2 * 4096; sI += 512) {
     const int g = sI >> 12, r = sI & 4095;        // g: 0 residual, 1 skip
@@ -347,8 +361,9 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const __amdgpu_buffer_rsrc_t sgb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.sg.p + (size_t)b * a.sg.sb), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ctx.p + (size_t)b * a.ctx.sb), 0, 0x7FFFFFFF, RSRC);
   const bool save = a.th.p != nullptr, has_out = a.xout.p != nullptr;
-  int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld;
+  int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld, cld4 = 4 * a.ctx.ld;
   // (row offsets = row * ld are re-formed where they are used, behind a fence on ld: hoisted out of
   // the strip loop the ~120 products filled the scalar file and were spilled to vector lanes)
 #define FS_FENCE(x) asm volatile("" : "+s"(x))
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     tc_ = live_ ? t_ : a.t_begin;  // (clamped: dead lanes read a valid column, zeroed afterwards)
   };
   float xb1[32];  // x(t) of the current strip: B operand of k-steps 32..63, residual input
-  {
+  if (!HAS_CTX) {
     bool lv;
     int tcc;
     column(tb + 32 * wave, lv, tcc);
@@ -387,6 +402,22 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     const int ox0 = 4 * (cbase * a.xin.ld + tc - a.d);
     const int oth = 4 * (cbase * a.th.ld + tc), oxo = 4 * (cbase * a.xout.ld + tc);
     const int osk = 4 * (cbase * a.skip.ld + (skip_live ? t : skip_lo));
+    float xn1[32];  // without context: x(t) of the NEXT strip; with: ctx(t) of this one (k-steps 64..95)
+    if (HAS_CTX) {
+      const int o1 = 4 * (cbase * a.xin.ld + tc), oc = 4 * (cbase * a.ctx.ld + tc);
+      FS_FENCE(xld4);
+      FS_FENCE(cld4);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+        xb1[j] = live ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cb, oc, ((j & 3) + 8 * (j >> 2)) * cld4, 0));
+        xn1[j] = live ? v : 0.f;
+      }
+    }
     // ---- x(t - d) of channel kc(j) + 4 lh: B operand of k-steps 0..31; later the skip accumulator's old values
     float xa0[32];
     FS_FENCE(xld4);
@@ -407,17 +438,17 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
-    for (int kq = 0; kq < 16; ++kq) {
-      const int k4 = kq < 8 ? 8 + kq : kq - 8;
+    for (int kq = 0; kq < NK1; ++kq) {
+      const int k4 = kq < 8 ? 8 + kq : kq < 16 ? kq - 8 : kq;  // x(t), x(t - d), context
       fsv4 aw[4];
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w1a + 4u * (unsigned)((blk * 16 + k4) * 256));
+      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w1a + 4u * (unsigned)((blk * NK1 + k4) * 256));
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
-          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[blk][e], k4 >= 8 ? xb1[4 * (k4 - 8) + e] : xa0[4 * k4 + e],
-                                                          acc[blk], 0, 0, 0);
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              aw[blk][e], k4 >= 16 ? xn1[4 * (k4 - 16) + e] : k4 >= 8 ? xb1[4 * (k4 - 8) + e] : xa0[4 * k4 + e], acc[blk], 0, 0, 0);
     }
     // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
     float z[32];
@@ -426,7 +457,9 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float tv = tanh_fast(acc[h][r]), sv = sigmoid_fast(acc[2 + h][r]);
+        const int cg_ = 32 * h + (r & 3) + 8 * (r >> 2) + cbase;
+        const float tv = tanh_fast(HAS_CTX ? acc[h][r] + BI[128 + cg_] : acc[h][r]);
+        const float sv = sigmoid_fast(HAS_CTX ? acc[2 + h][r] + BI[192 + cg_] : acc[2 + h][r]);
         z[16 * h + r] = tv * sv;
         if (save && live) {
           const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
@@ -445,9 +478,9 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
           xa0[16 * h + r] = __uint_as_float(
               __builtin_amdgcn_raw_buffer_load_b32(skb, osk, (32 * h + (r & 3) + 8 * (r >> 2)) * skld4, 0));
     }
-    float xn1[32];
-    const bool more = t0 + 32 * 8 < te;
-    if (more) {
+    const bool more = !HAS_CTX && t0 + 32 * 8 < te;
+    if (HAS_CTX) {
+    } else if (more) {
       bool lv;
       int tcc;
       column(t0 + 32 * 8, lv, tcc);
@@ -506,8 +539,10 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a.first_layer ? v : xa0[16 * h + r] + v), skb, osk, k0 * skld4, 0);
         }
     }
+    if (!HAS_CTX) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) xb1[j] = xn1[j];
+      for (int j = 0; j < 32; ++j) xb1[j] = xn1[j];
+    }
   }
 }
 
@@ -516,11 +551,15 @@ static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t 
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
   fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);  // a chunk: whole rounds of the 8 waves' strips
-  const void *fn = (const void *)fused_layer64s_kernel;
+  const bool has_ctx = a.ctx.p != nullptr;
+  const void *fn = has_ctx ? (const void *)fused_layer64s_kernel<true> : (const void *)fused_layer64s_kernel<false>;
   const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(fused_layer64s)");
   if (rc) return rc;
-  hipLaunchKernelGGL(fused_layer64s_kernel, dim3(chunks * batch), dim3(512), FS_LDS_FLOATS * sizeof(float), s, a, chunks,
-                     chunk_t);
+  const size_t lds = ((has_ctx ? 24576 : 16384) + 8192 + 256) * sizeof(float);
+  if (has_ctx)
+    hipLaunchKernelGGL(fused_layer64s_kernel<true>, dim3(chunks * batch), dim3(512), lds, s, a, chunks, chunk_t);
+  else
+    hipLaunchKernelGGL(fused_layer64s_kernel<false>, dim3(chunks * batch), dim3(512), lds, s, a, chunks, chunk_t);
   return MVN_OK;
 }
 
@@ -658,6 +697,7 @@ static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_
 }
 // The strip kernel is the default; MOVENET_HIP_FORWARD_TILE=32 / 64 select the tile kernels (A/B, tests)
 static int launch_fused_layer64p(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+  if (a.ctx.p) return launch_fused_layer64s(a, batch, s);  // conditioned: the strip kernel only (the caller checks the row length)
   const char *e = getenv("MOVENET_HIP_FORWARD_TILE");
   if (e && e[0] == '6') return launch_fused_layer64p_t<2>(a, batch, s);
   if (e && e[0] == '3') return launch_fused_layer64p_t<1>(a, batch, s);

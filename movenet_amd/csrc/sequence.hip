@@ -857,8 +857,13 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       const char *e = getenv("MOVENET_HIP_NO_PERSISTENT_FORWARD");
       return e && e[0] == '1';
     }();
-    if (C == FL_C && Kc == FL_C && !has_ctx && !f16 && !no_fused && !no_persistent) {
+    if (C == FL_C && Kc == FL_C && !f16 && !no_fused && !no_persistent &&
+        (!has_ctx || (g.Tp <= (1 << 22) && buf->ctx_ld <= (1 << 22)))) {
       FusedFwdPArgs fp;
+      if (has_ctx) {  // conditioned layer: the strip kernel with the context as a third K block
+        fp.wcf = p->ctx_filter_w[l]; fp.wcg = p->ctx_gate_w[l]; fp.bcf = p->ctx_filter_b[l]; fp.bcg = p->ctx_gate_b[l];
+        fp.ctx = ctxv;
+      }
       fp.t_begin = A + d; fp.t_end = T; fp.d = d; fp.t_skip0 = t_skip0; fp.t_base = g.t_base;
       fp.first_layer = (l == 0);
       fp.wf = p->filter_w[l]; fp.wg = p->gate_w[l]; fp.wr = p->residual_w[l]; fp.ws = p->skip_w[l];
