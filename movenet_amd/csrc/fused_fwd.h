@@ -304,6 +304,15 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
 // ----------------------------------------------------------------------------------------
 // HAS_CTX: the conditioned layer -- the context is a third K block of the first product (96 KB of
 // f|g weights), its 32 registers are the ones the unconditioned kernel uses to fetch x(t) a strip ahead.
+#ifndef MVN_EXP
+#define MVN_EXP 0  // timing experiments (wrong results): 11 no x(t-d) loads after a wave's first strip, 12 + no skip
+#endif             // loads, 13 no stores, 14 = 12 + 13
+// Strips start at multiples of 32 columns of the absolute time axis (rows are 256-byte aligned: every
+// 128-byte row segment a store instruction writes is ONE cache line, not two halves: 148.6 -> 142.4 us
+// per layer), and tanh / sigmoid -- written once, read by the backward pass much later -- leave with
+// the non-temporal hint (-> 135.8 us; on x' and the skip sums, which the next layer reads, it costs 5 us).
+constexpr int FS_ALIGN = 31;
+constexpr int FS_AUX_SAVE = 2;  // nt
 template <bool HAS_CTX>
 __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
   constexpr int C = 64, NK1 = HAS_CTX ? 24 : 16, W1_F = 4 * NK1 * 256;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5;
-  const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int tb = (a.t_begin & ~FS_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const int skip_lo = max(a.t_begin, a.t_skip0);
   // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4].  The loop runs over the SOURCE
   // elements (coalesced reads of the (out, in, tap) / (out, in) tensors) and scatters into LDS.
@@ -362,7 +371,12 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ctx.p + (size_t)b * a.ctx.sb), 0, 0x7FFFFFFF, RSRC);
-  const bool save = a.th.p != nullptr, has_out = a.xout.p != nullptr;
+#if MVN_EXP == 13 || MVN_EXP == 14
+  const bool st_ok = a.d < 0;  // (never: the stores stay in the code, none is executed)
+#else
+  constexpr bool st_ok = true;
+#endif
+  const bool save = st_ok && a.th.p != nullptr, has_out = st_ok && a.xout.p != nullptr;
   int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld, cld4 = 4 * a.ctx.ld;
   // (row offsets = row * ld are re-formed where they are used, behind a fence on ld: hoisted out of
   // the strip loop the ~120 products filled the scalar file and were spilled to vector lanes)
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     bool live;
     int tc;
     column(t0, live, tc);
-    const bool skip_live = t >= skip_lo && t < te;
+    const bool skip_live = st_ok && t >= skip_lo && t < te;
     // per-lane byte offsets (channel part 4 lh of the row + the column)
     const int ox0 = 4 * (cbase * a.xin.ld + tc - a.d);
     const int oth = 4 * (cbase * a.th.ld + tc), oxo = 4 * (cbase * a.xout.ld + tc);
@@ -421,6 +435,12 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     // ---- x(t - d) of channel kc(j) + 4 lh: B operand of k-steps 0..31; later the skip accumulator's old values
     float xa0[32];
     FS_FENCE(xld4);
+#if MVN_EXP == 11 || MVN_EXP == 12 || MVN_EXP == 14
+    if (t0 != tb + 32 * wave) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xa0[j] = xb1[j] * 0.5f;
+    } else
+#endif
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
@@ -463,14 +483,18 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
         z[16 * h + r] = tv * sv;
         if (save && live) {
           const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, FS_AUX_SAVE);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, FS_AUX_SAVE);
         }
       }
     // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's
     // x(t), both under the MFMAs below
     FS_FENCE(skld4);
+#if MVN_EXP == 12 || MVN_EXP == 14
+    if (false) {
+#else
     if (!a.first_layer) {
+#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -547,7 +571,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
 }
 
 static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t s) {
-  const int nt = a.t_end - (a.t_begin & ~3);
+  const int nt = a.t_end - (a.t_begin & ~FS_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
   fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);  // a chunk: whole rounds of the 8 waves' strips
