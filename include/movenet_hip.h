@@ -178,10 +178,10 @@ int mvn_transpose_context(const float *ctx, int ctx_ld, int batch, int channels,
  * (batch, channels, Tp) with Tp = mvn_padded_len(T) and column t = input time
  * t; layer l's input is valid for t >= A_l (A_0 = 0, A_{l+1} = A_l + d_l), so
  * the reference's right-aligned slices (modules.py:84, :91) become "same t".
- * Skip/head tensors are (batch, channels, Sp), Sp = mvn_padded_len(S + 3),
- * S = T - RF + 1; the column of time t is t - ((RF-1) & ~3), i.e. the S valid
- * columns start at column (RF-1) & 3, so that column == t (mod 4) and 16-byte
- * accesses stay aligned on both time axes.
+ * Skip/head tensors are (batch, channels, Sp), Sp = mvn_padded_len(S + 31),
+ * S = T - RF + 1; the column of time t is t - ((RF-1) & ~31), i.e. the S valid
+ * columns start at column (RF-1) & 31, so that column == t (mod 32): 16-byte
+ * accesses and the 128-byte cache lines line up on both time axes.
  * ------------------------------------------------------------------------ */
 int mvn_padded_len(int n); /* n rounded up to a multiple of 64 */
 
@@ -257,7 +257,7 @@ typedef struct mvn_bwd_buffers {
 /* dout: gradient w.r.t. mvn_forward's `out` (same shape); `out` itself is needed
  * when normalize != 0 (softmax backward).  dout == NULL: the caller has already written the
  * gradient w.r.t. the LOGITS into bwd->dlogit (layout (B, Q, Sp), the column of output
- * position s is s + ((RF-1) & 3), columns of positions >= S_out zero) -- what
+ * position s is s + ((RF-1) & 31), columns of positions >= S_out zero) -- what
  * mvn_softmax_ce_backward does.  Requires the forward ran with save.
  * Part of the work is enqueued on a stream the library owns (one per device) and joined
  * back into `stream` with events before the call returns: to the caller it is ordinary

@@ -45,7 +45,6 @@ static int fb_device_cus() {
 // Tiles start at multiples of 32 columns of the absolute time axis: the 256-byte row segments of a
 // tile are two whole cache lines (first half 110 -> 103 us per layer, second 172.5 -> 169.8).
 // (Non-temporal loads of the saved activations changed nothing.)
-constexpr int FB_ALIGN = 31;
 
 static void fb_chunks(int nt, int batch, int per_cu, int *chunks, int *chunk_t, int tile = W2_T) {
   const int tiles = (nt + tile - 1) / tile;
@@ -66,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
-  const int tb = (a.t_begin & ~FB_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const int skip_lo = max(a.t_begin, a.t_skip0);
   const bool has_dxo = a.dxo.p != nullptr;
 
@@ -243,34 +242,23 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
   }
 }
 
-// The first half's two reductions in ONE launch (slab_reduce_kernel's scheme: 32 elements x 8 slab
-// segments per workgroup, fixed order): workgroups [0, 256) take the 128 x 64 weight-gradient
+// The first half's two reductions in ONE launch (slab_reduce_kernel's scheme: 32 elements x RED_SEG
+// slab segments per workgroup, fixed order): workgroups [0, 256) take the 128 x 64 weight-gradient
 // elements, [256, 260) the 128 bias sums.
 template <class Op>
-__global__ __launch_bounds__(256) void reduce_rs64_kernel(Op op, const float *__restrict__ part,
-                                                          const float *__restrict__ bias_part, int nparts) {
-  __shared__ float red[8][32];
+__global__ __launch_bounds__(32 * RED_SEG) void reduce_rs64_kernel(Op op, const float *__restrict__ part,
+                                                                    const float *__restrict__ bias_part, int nparts) {
+  __shared__ float red[RED_SEG][32];
   const int e = threadIdx.x & 31, seg = threadIdx.x >> 5;
   const bool is_bias = blockIdx.x >= 256;
   const size_t stride = is_bias ? 128 : (size_t)128 * 64;
   const size_t idx = is_bias ? (size_t)(blockIdx.x - 256) * 32 + e : (size_t)blockIdx.x * 32 + e;
-  const float *src = is_bias ? bias_part : part;
-  const int per = (nparts + 7) / 8, p0 = seg * per, p1 = min(nparts, p0 + per);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int q = p0;
-  for (; q + 3 < p1; q += 4) {
-    s0 += src[(size_t)q * stride + idx];
-    s1 += src[(size_t)(q + 1) * stride + idx];
-    s2 += src[(size_t)(q + 2) * stride + idx];
-    s3 += src[(size_t)(q + 3) * stride + idx];
-  }
-  for (; q < p1; ++q) s0 += src[(size_t)q * stride + idx];
-  red[seg][e] = (s0 + s1) + (s2 + s3);
+  red[seg][e] = slab_segment_sum(is_bias ? bias_part : part, stride, idx, nparts, seg);
   __syncthreads();
   if (seg == 0) {
     float t = red[0][e];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][e];
+    for (int k = 1; k < RED_SEG; ++k) t += red[k][e];
     float *dst = is_bias ? op.db((int)idx) : op.dw((int)(idx >> 6), (int)(idx & 63));
     if (dst) *dst += t;
   }
@@ -282,14 +270,14 @@ __global__ __launch_bounds__(256) void reduce_rs64_kernel(Op op, const float *__
 template <class WgOp>
 static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int batch, float *bias_scratch,
                                  float *slab, size_t slab_floats, hipStream_t s) {
-  const int nt = a.t_end - (a.t_begin & ~FB_ALIGN);
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return true;
   int chunks, chunk_t;
   fb_chunks(nt, batch, 2, &chunks, &chunk_t);
   const size_t need = (size_t)chunks * batch * 128 * 64;
   if (!bias_scratch || !slab || need > slab_floats) return false;
   hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, chunk_t, bias_scratch, slab);
-  hipLaunchKernelGGL(reduce_rs64_kernel<WgOp>, dim3(256 + 4), dim3(256), 0, s, op, slab, bias_scratch, chunks * batch);
+  hipLaunchKernelGGL(reduce_rs64_kernel<WgOp>, dim3(256 + 4), dim3(32 * RED_SEG), 0, s, op, slab, bias_scratch, chunks * batch);
   return true;
 }
 
@@ -329,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
-  const int tb = (a.t_out0 & ~FB_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int tb = (a.t_out0 & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const bool has_dxo = a.dxo.p != nullptr;
 
   // ---- dx: wave -> (tap half, 32 u x 32 c block); B operand W_tap[o][32 wc + li], o = 2 kk + lh
@@ -511,7 +499,7 @@ template <class WgOp>
 static int launch_bwd_dx_wgfg64(const FusedBwdBArgs &a, const WgOp &op, int batch, float *slab,
                                 size_t slab_floats, hipStream_t s, bool *done) {
   *done = false;
-  const int nt = a.t_end - (a.t_out0 & ~FB_ALIGN);
+  const int nt = a.t_end - (a.t_out0 & ~TILE_ALIGN);
   if (a.t_end <= a.t_out0 || batch <= 0) {
     *done = true;
     return MVN_OK;
@@ -525,7 +513,7 @@ static int launch_bwd_dx_wgfg64(const FusedBwdBArgs &a, const WgOp &op, int batc
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_dx_wgfg64_kernel, dim3(chunks * batch), dim3(512), FBB_LDS_FLOATS * sizeof(float), s, a,
                      chunks, chunk_t, slab);
-  hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 128 / 32), dim3(256), 0, s, op, slab, chunks * batch, 128, 128);
+  hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 128 / 32), dim3(32 * RED_SEG), 0, s, op, slab, chunks * batch, 128, 128);
   *done = true;
   return MVN_OK;
 }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
-  const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const int skip_lo = max(a.t_begin, a.t_skip0);
 
   // ---- the weights reach their registers through LDS: a lane's values lie 512 (256) bytes apart
@@ -311,7 +311,6 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
 // 128-byte row segment a store instruction writes is ONE cache line, not two halves: 148.6 -> 142.4 us
 // per layer), and tanh / sigmoid -- written once, read by the backward pass much later -- leave with
 // the non-temporal hint (-> 135.8 us; on x' and the skip sums, which the next layer reads, it costs 5 us).
-constexpr int FS_ALIGN = 31;
 constexpr int FS_AUX_SAVE = 2;  // nt
 template <bool HAS_CTX>
 __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
@@ -322,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5;
-  const int tb = (a.t_begin & ~FS_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const int skip_lo = max(a.t_begin, a.t_skip0);
   // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4].  The loop runs over the SOURCE
   // elements (coalesced reads of the (out, in, tap) / (out, in) tensors) and scatters into LDS.
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
 }
 
 static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t s) {
-  const int nt = a.t_end - (a.t_begin & ~FS_ALIGN);
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
   fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);  // a chunk: whole rounds of the 8 waves' strips
@@ -617,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int m_base = blockIdx.y * M;
   const int li = lane & 31, lh = lane >> 5;
-  const int tb = (a.t_begin & ~3) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   for (int r = tid; r < K * M; r += 512) {  // source order: coalesced
     const int m = TRANSPOSED ? r % M : r / K, k = TRANSPOSED ? r / M : r % K;
     const int kk = k >> 1;
@@ -694,7 +693,7 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
 // `m_total` output rows = m_total / M row blocks
 template <int K, int M, int IN, int OUT, bool TRANSPOSED>
 static int launch_dense_strip(const DenseStripArgs &a, int m_total, int batch, hipStream_t s) {
-  const int nt = a.t_end - (a.t_begin & ~3);
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
   fb_chunks(nt, batch * (m_total / M), 1, &chunks, &chunk_t, 256);
@@ -709,7 +708,7 @@ static int launch_dense_strip(const DenseStripArgs &a, int m_total, int batch, h
 template <int NTB>
 static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_t s) {
   constexpr int TT = 32 * NTB, LDS_BYTES = (2 * 128 + 3 * 64) * (TT + 4) * (int)sizeof(float);
-  const int nt = a.t_end - (a.t_begin & ~3);
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
   int chunks, chunk_t;
   fb_chunks(nt, batch, NTB == 1 ? 2 : 1, &chunks, &chunk_t, TT);  // one round of workgroups (fused_bwd.h)

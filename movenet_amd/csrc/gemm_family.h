@@ -7,6 +7,12 @@
 
 namespace mvn {
 
+// Every tiled kernel starts its tiles at a multiple of 32 columns of the tensors' time axis (rows
+// are 256-byte aligned): the 128-byte row segments the loads and stores of a tile touch are whole
+// cache lines.  (Columns in front of an op's t_begin are masked as before.)
+constexpr int TILE_ALIGN = 31;
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Act {  // (B, ch, ld) view
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_staged_kernel(Op op) {
   // operand accessors' branches on them) on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, mb = blockIdx.y;
-  const int t0 = (op.t_begin & ~3) + blockIdx.x * 256;
+  const int t0 = (op.t_begin & ~TILE_ALIGN) + blockIdx.x * 256;
   const int nchunk = (op.K + GX_KC - 1) / GX_KC;
 
   f32x16 acc[2][2];
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wx_staged_f16_kernel(Op op) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, mb = blockIdx.y;
-  const int t0 = (op.t_begin & ~3) + blockIdx.x * 256;
+  const int t0 = (op.t_begin & ~TILE_ALIGN) + blockIdx.x * 256;
   const int nchunk = (op.K + GX_KC - 1) / GX_KC;
 
   f32x16 acc[2][2];
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int mblk = blockIdx.y / nblk_n, nblk = blockIdx.y - mblk * nblk_n;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tb = (op.t_begin & ~3) + ch * W2_CHUNK, te = min(op.t_end, tb + W2_CHUNK);
+  const int tb = (op.t_begin & ~TILE_ALIGN) + ch * W2_CHUNK, te = min(op.t_end, tb + W2_CHUNK);
 
   f32x16 acc[2][NB];
 #pragma unroll
@@ -658,31 +664,50 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
 }
 
 // dW(m,n) += sum over the workgroups' slabs, in a fixed order (deterministic, and ~10x cheaper
-// than the 8 M float atomics the slabs replace at config 2).  Workgroup = 32 elements x 8
-// slab segments; one thread per element does the final read-modify-write.
+// than the 8 M float atomics the slabs replace at config 2).  Workgroup = 32 elements x RED_SEG
+// slab segments (1024 threads: the kernel is a latency chain of strided loads, so every thread
+// keeps its whole share of <= 16 loads in flight when the launch has <= 512 slabs); one thread
+// per element does the final read-modify-write.
+constexpr int RED_SEG = 32;
+__device__ __forceinline__ float slab_segment_sum(const float *__restrict__ src, size_t stride, size_t idx, int nparts,
+                                                  int seg) {
+  const int per = (nparts + RED_SEG - 1) / RED_SEG, p0 = seg * per, p1 = min(nparts, p0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = p0;
+  for (; q + 15 < p1; q += 16) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = src[(size_t)(q + i) * stride + idx];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      s0 += v[i];
+      s1 += v[i + 1];
+      s2 += v[i + 2];
+      s3 += v[i + 3];
+    }
+  }
+  for (; q + 3 < p1; q += 4) {
+    s0 += src[(size_t)q * stride + idx];
+    s1 += src[(size_t)(q + 1) * stride + idx];
+    s2 += src[(size_t)(q + 2) * stride + idx];
+    s3 += src[(size_t)(q + 3) * stride + idx];
+  }
+  for (; q < p1; ++q) s0 += src[(size_t)q * stride + idx];
+  return (s0 + s1) + (s2 + s3);
+}
 template <class Op>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(Op op, const float *__restrict__ part,
-                                                          int nparts, int m_rows_pad, int n_cols_pad) {
-  __shared__ float red[8][32];
+__global__ __launch_bounds__(32 * RED_SEG) void slab_reduce_kernel(Op op, const float *__restrict__ part,
+                                                                    int nparts, int m_rows_pad, int n_cols_pad) {
+  __shared__ float red[RED_SEG][32];
   const int e = threadIdx.x & 31, seg = threadIdx.x >> 5;
   const size_t mn = (size_t)m_rows_pad * n_cols_pad;
   const size_t idx = (size_t)blockIdx.x * 32 + e;
-  const int per = (nparts + 7) / 8, p0 = seg * per, p1 = min(nparts, p0 + per);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int q = p0;
-  for (; q + 3 < p1; q += 4) {
-    s0 += part[(size_t)q * mn + idx];
-    s1 += part[(size_t)(q + 1) * mn + idx];
-    s2 += part[(size_t)(q + 2) * mn + idx];
-    s3 += part[(size_t)(q + 3) * mn + idx];
-  }
-  for (; q < p1; ++q) s0 += part[(size_t)q * mn + idx];
-  red[seg][e] = (s0 + s1) + (s2 + s3);
+  red[seg][e] = slab_segment_sum(part, mn, idx, nparts, seg);
   __syncthreads();
   if (seg == 0) {
     float t = red[0][e];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][e];
+    for (int k = 1; k < RED_SEG; ++k) t += red[k][e];
     const int m = (int)(idx / n_cols_pad), n = (int)(idx - (size_t)m * n_cols_pad);
     float *dst = op.dw(m, n);
     if (dst) *dst += t;
@@ -721,7 +746,7 @@ static void launch_gemm(const Op &op, int m_rows, int batch, hipStream_t s) {
 // bias_scratch: >= chunks*batch*64*ceil(m_rows/64) floats, or NULL when the op has no bias
 template <class Op>
 static void launch_gemm_staged(const Op &op, int m_rows, int batch, hipStream_t s) {
-  const int nt = op.t_end - (op.t_begin & ~3);
+  const int nt = op.t_end - (op.t_begin & ~TILE_ALIGN);
   if (op.t_end <= op.t_begin || batch <= 0) return;
   dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
   hipLaunchKernelGGL(gemm_wx_staged_kernel<Op>, grid, dim3(256), 0, s, op);
@@ -731,7 +756,7 @@ static void launch_gemm_staged(const Op &op, int m_rows, int batch, hipStream_t 
 template <class Op>
 static void launch_gemm_staged(const Op &op, int m_rows, int batch, hipStream_t s, bool f16) {
   if (!f16) return launch_gemm_staged(op, m_rows, batch, s);
-  const int nt = op.t_end - (op.t_begin & ~3);
+  const int nt = op.t_end - (op.t_begin & ~TILE_ALIGN);
   if (op.t_end <= op.t_begin || batch <= 0) return;
   dim3 grid((nt + 255) / 256, (m_rows + 63) / 64, batch);
   hipLaunchKernelGGL(gemm_wx_staged_f16_kernel<Op>, grid, dim3(256), 0, s, op);
@@ -759,7 +784,7 @@ static void launch_wgrad(const Op &op, int m_rows, int n_rows, int batch, float 
 template <int NB, class Op>
 static void launch_wgrad2(const Op &op, int m_rows, int n_rows, int batch, float *bias_scratch,
                           float *slab_scratch, size_t slab_floats, hipStream_t s) {
-  const int nt = op.t_end - (op.t_begin & ~3);
+  const int nt = op.t_end - (op.t_begin & ~TILE_ALIGN);
   if (op.t_end <= op.t_begin || batch <= 0) return;
   const int chunks = (nt + W2_CHUNK - 1) / W2_CHUNK;
   const int mb = (m_rows + 127) / 128, nb = (n_rows + 64 * NB - 1) / (64 * NB);
@@ -770,7 +795,7 @@ static void launch_wgrad2(const Op &op, int m_rows, int n_rows, int batch, float
   hipLaunchKernelGGL((wgrad2_kernel<Op, NB>), grid, dim3(256), 0, s, op, nb, chunks, bias_scratch,
                      mpad, part, npad);
   if (part)
-    hipLaunchKernelGGL(slab_reduce_kernel<Op>, dim3(mpad * npad / 32), dim3(256), 0, s, op, part,
+    hipLaunchKernelGGL(slab_reduce_kernel<Op>, dim3(mpad * npad / 32), dim3(32 * RED_SEG), 0, s, op, part,
                        chunks * batch, mpad, npad);
   if (bias_scratch)
     hipLaunchKernelGGL(bias_reduce_kernel<Op>, dim3(mpad), dim3(64), 0, s, op, bias_scratch,

@@ -518,7 +518,7 @@ struct WgDenseOp {
     return (m < M && n < N) ? dwm + (size_t)m * N + n : nullptr;
   }
   __device__ __forceinline__ float *db(int m) const { return m < M ? dbv + m : nullptr; }
-  // row descriptors for wgrad2 (the head's column axis starts at t_begin = pad < 4)
+  // row descriptors for wgrad2 (the head's column axis starts at t_begin = pad < 32)
   static constexpr bool X_PRODUCT = false;
   static constexpr bool HAS_BIAS = true;
   static constexpr bool X_ABSENT_ROWS = false;
@@ -709,9 +709,9 @@ __global__ void ring_fill_kernel(const float *__restrict__ acts, long long act_s
 // ======================================================================
 struct Geometry {
   int L, C, Kc, Q, T, Tp, S, Sp, rf;
-  int pad, t_base;  // skip/head tensors: column of time t = t - t_base, t_base = (RF-1) & ~3,
-                    // so that column == t (mod 4): float4 accesses stay aligned; the first
-                    // valid column is pad = (RF-1) & 3
+  int pad, t_base;  // skip/head tensors: column of time t = t - t_base, t_base = (RF-1) & ~31,
+                    // so that column == t (mod 32): float4 accesses and cache lines line up on
+                    // both axes; the first valid column is pad = (RF-1) & 31
   long long act;   // floats per (B,C,Tp) tensor
   long long skp;   // floats per (B,Kc,Sp)
   long long hid;   // floats per (B,Q,Sp)
@@ -733,9 +733,9 @@ static int make_geometry(const mvn_dims *d, int batch, int t_len, Geometry &g) {
   g.S = mvn_output_size(d, t_len);
   if (g.S < 0) return g.S;
   g.Tp = mvn_padded_len(t_len);
-  g.pad = (g.rf - 1) & 3;
+  g.pad = (g.rf - 1) & 31;
   g.t_base = (g.rf - 1) - g.pad;
-  g.Sp = mvn_padded_len(g.S + 3);
+  g.Sp = mvn_padded_len(g.S + 31);
   g.act = (long long)batch * g.C * g.Tp;
   g.skp = (long long)batch * g.Kc * g.Sp;
   g.hid = (long long)batch * g.Q * g.Sp;
@@ -1013,7 +1013,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   float *bias_scratch2 = nullptr, *slab = bwd->da1;
   size_t slab_floats = (size_t)batch * Q * g.Sp;
   {
-    const size_t need = (size_t)((T + 3 + W2_CHUNK - 1) / W2_CHUNK) * batch * ((C + Kc + 127) / 128 * 128);
+    const size_t need = (size_t)((T + TILE_ALIGN + W2_CHUNK - 1) / W2_CHUNK) * batch * ((C + Kc + 127) / 128 * 128);
     if (need <= slab_floats / 2) {
       slab_floats -= need;
       bias_scratch2 = bwd->da1 + slab_floats;
@@ -1024,7 +1024,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   size_t head_slab_floats = (size_t)batch * 2 * C * g.Tp;
   bool head_scratch_ok = false;
   {
-    const size_t chunks = (size_t)(g.S + 3 + W2_CHUNK - 1) / W2_CHUNK;
+    const size_t chunks = (size_t)(g.S + TILE_ALIGN + W2_CHUNK - 1) / W2_CHUNK;
     const size_t mpad = (size_t)(Q + 127) / 128 * 128;
     const size_t need_bias = chunks * batch * mpad, need_slab = chunks * batch * mpad * mpad;
     if (need_bias + need_slab <= head_slab_floats) {

@@ -49,7 +49,7 @@ class ForwardBuffers:
         L = dims.layer_size * dims.stack_size
         C, K, Q = dims.residual_channels, dims.skip_channels, dims.input_channels
         S = N.check(lib.mvn_output_size(dims, t_len), "mvn_output_size")
-        self.S, self.Tp, self.Sp = S, lib.mvn_padded_len(t_len), lib.mvn_padded_len(S + 3)
+        self.S, self.Tp, self.Sp = S, lib.mvn_padded_len(t_len), lib.mvn_padded_len(S + 31)
         f32 = dict(dtype=torch.float32, device=device)
         self.acts = torch.empty(((L + 1) if save else 2, batch, C, self.Tp), **f32)
         self.th = torch.empty((L, batch, C, self.Tp), **f32) if save else None
@@ -171,7 +171,7 @@ def _run_backward(ctx_, params, out, dout, fill_dlogit):
                           None if dctx is None else dctx.data_ptr())
         if fill_dlogit is not None:
             rf = N.check(lib.mvn_receptive_fields(dims), "mvn_receptive_fields")
-            fill_dlogit(dlogit, buf.Sp, (rf - 1) & 3)
+            fill_dlogit(dlogit, buf.Sp, (rf - 1) & 31)
         params_c, pkeep = pack_params(dims, sd, L)
         N.check(lib.mvn_backward(dims, params_c, g, None if dense_in else idx.data_ptr(),
                                  0 if dense_in else idx.stride(0), B, T,
