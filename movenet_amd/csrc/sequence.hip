@@ -553,10 +553,11 @@ __global__ void embed_kernel(const float *__restrict__ cw, const int32_t *__rest
 // slice [cg][Q][2] (ds_add_f32: lanes walk t, so a collision needs two lanes of one wave
 // on the same class); the slice is then added to HBM once -- T/EG_CHUNK times fewer
 // global atomics than one per (channel, time step).
-constexpr int EG_CHUNK = 2048;
-__global__ __launch_bounds__(256) void embed_grad_kernel(float *__restrict__ dcw,
+constexpr int EG_CHUNK = 1024;
+__global__ __launch_bounds__(1024) void embed_grad_kernel(float *__restrict__ dcw,
                                                          const int32_t *__restrict__ idx, int idx_stride,
-                                                         Act dx0, int C, int Q, int T, int cg) {
+                                                         Act dx0, int C, int Q, int T, int cg,
+                                                         float *__restrict__ part) {
   extern __shared__ float tab[];  // [cg][Q][2]
   const int b = blockIdx.z, c0 = blockIdx.y * cg, t0 = blockIdx.x * EG_CHUNK;
   const int nc = min(cg, C - c0), t1 = min(T, t0 + EG_CHUNK);
@@ -565,18 +566,130 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(float *__restrict__ dcw
   const int32_t *ib = idx + (size_t)b * idx_stride;
   for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
     const int q1 = min(max(ib[t], 0), Q - 1), q0 = t > 0 ? min(max(ib[t - 1], 0), Q - 1) : -1;
-    for (int c = 0; c < nc; ++c) {
+    // eight channels' loads in flight per thread (one at a time, each in front of its two LDS
+    // atomics, the kernel was a chain of load latencies: 183 us for 65 MB)
+    int c = 0;
+    for (; c + 8 <= nc; c += 8) {
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = *dx0.at(b, c0 + c + j, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&tab[((c + j) * Q + q1) * 2 + 1], g[j]);
+        if (q0 >= 0) atomicAdd(&tab[((c + j) * Q + q0) * 2 + 0], g[j]);
+      }
+    }
+    for (; c < nc; ++c) {
       const float g = *dx0.at(b, c0 + c, t);
       atomicAdd(&tab[(c * Q + q1) * 2 + 1], g);
       if (q0 >= 0) atomicAdd(&tab[(c * Q + q0) * 2 + 0], g);
     }
   }
   __syncthreads();
+  if (part) {
+    // this workgroup's slice of table copy (chunk, sequence); slab_reduce_kernel adds the copies up.
+    // (Flushed with atomics, the 128 workgroups per table word queued up at the memory side:
+    // 4.2 M device-scope float atomics took ~150 of the kernel's 181 us.)
+    float *dst = part + ((size_t)blockIdx.x * gridDim.z + b) * ((size_t)C * Q * 2) + (size_t)c0 * Q * 2;
+    for (int i = threadIdx.x; i < nc * Q * 2; i += blockDim.x) dst[i] = tab[i];
+    return;
+  }
   for (int i = threadIdx.x; i < nc * Q * 2; i += blockDim.x) {
     const float v = tab[i];
     if (v != 0.f) atomicAdd(dcw + (size_t)c0 * Q * 2 + i, v);
   }
 }
+// The same scatter-add for C = 64 without atomics: LANES ARE CHANNELS, ONE WAVE PER WORKGROUP.
+// ds_add_f32 costs ~3 cycles per LANE on this chip (32.8 M lane-atomics = the 171 us of the
+// kernel above, whatever the bank pattern: the same time with conflict-free addresses).  Here a
+// wave owns the LDS table of one tap, [class][channel] (64 KB): the class of a time step is a
+// scalar, the 64 lanes read-modify-write 64 consecutive words with plain ds_read / ds_write, and
+// LDS operations of one wave execute in order.  Four steps are in flight at a time; equal
+// classes among them are merged first (scalar compares), so no update is lost.  A lane fetches
+// four steps of its row with one 16-byte load, eight such groups a block ahead.
+constexpr int EG64_CHUNK = 1024, EG64_PARTS = 1;
+__global__ __launch_bounds__(64) void embed_grad64_kernel(const int32_t *__restrict__ idx, int idx_stride,
+                                                          Act dx0, int Q, int T, float *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // [Q / EG64_PARTS][64]
+  // (EG64_PARTS > 1 splits the classes of a tap over several workgroups, each scanning every step:
+  // measured slower with 4 -- the per-group instruction stream is the cost, not the LDS latency)
+  const int b = blockIdx.y, tap = blockIdx.z / EG64_PARTS, prt = blockIdx.z % EG64_PARTS, lane = threadIdx.x;
+  const int QP = Q / EG64_PARTS, qbase = prt * QP;
+  const int t0 = blockIdx.x * EG64_CHUNK, t1 = min(T, t0 + EG64_CHUNK);
+  for (int i = lane; i < QP * 16; i += 64) ((f4 *)tab)[i] = kZero4;
+  __syncthreads();
+  const int32_t *ib = idx + (size_t)b * idx_stride;
+  const float *row = dx0.at(b, lane, 0);
+  // (rows are padded to a multiple of 64 steps: a 16-byte load at a multiple of 4 below the row
+  // length is always inside the row; steps at or beyond t1 carry class -1 and are not used)
+  const int t_last = dx0.ld - 4;
+  auto fetch = [&](int t) -> f4 { return ldg4(row + min(t, t_last)); };
+  // class of step t0 + i for this tap (tap 1: idx[t], tap 0: idx[t - 1]; -1 = no contribution), staged
+  // in LDS once: fetched from global memory per group the index loads were a chain of 256 L2
+  // round trips per wave -- the whole 165 us of the first build of this kernel
+  int *sidx = (int *)(tab + (size_t)QP * 64);
+  for (int i = lane; i < EG64_CHUNK; i += 64) {
+    const int t = t0 + i, u = t - 1 + tap;
+    const int q = (t < t1 && u >= 0) ? min(max(ib[u], 0), Q - 1) - qbase : -1;
+    sidx[i] = q < QP ? q : -1;
+  }
+  __syncthreads();
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  // eight groups of four steps (8 x 16 bytes per lane) are fetched a block ahead
+  constexpr int NG = 8;
+  f4 nxt[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) nxt[k] = fetch(t0 + 4 * k);
+  for (int tb = t0; tb < t1; tb += 4 * NG) {
+    f4 cur[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) cur[k] = nxt[k];
+    if (tb + 4 * NG < t1) {
+#pragma unroll
+      for (int k = 0; k < NG; ++k) nxt[k] = fetch(tb + 4 * NG + 4 * k);
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int t = tb + 4 * k;
+      if (t >= t1) break;
+      const f4 v = cur[k];
+      const i4 qv = *(const i4 *)&sidx[t - t0];
+      const int q0 = __builtin_amdgcn_readfirstlane(qv.x), q1 = __builtin_amdgcn_readfirstlane(qv.y);
+      const int q2 = __builtin_amdgcn_readfirstlane(qv.z), q3 = __builtin_amdgcn_readfirstlane(qv.w);
+      float g0 = v.x, g1 = v.y, g2 = v.z, g3 = v.w;
+      // merge equal classes into the first step that has them
+      const bool d1 = q1 == q0;
+      if (d1) g0 += g1;
+      const bool d2 = q2 == q0 || q2 == q1;
+      if (q2 == q0) g0 += g2; else if (q2 == q1) g1 += g2;
+      const bool d3 = q3 == q0 || q3 == q1 || q3 == q2;
+      if (q3 == q0) g0 += g3; else if (q3 == q1) g1 += g3; else if (q3 == q2) g2 += g3;
+      const bool l0 = q0 >= 0, l1 = q1 >= 0 && !d1, l2 = q2 >= 0 && !d2, l3 = q3 >= 0 && !d3;
+      float *p0 = tab + (l0 ? q0 : 0) * 64 + lane, *p1 = tab + (l1 ? q1 : 0) * 64 + lane;
+      float *p2 = tab + (l2 ? q2 : 0) * 64 + lane, *p3 = tab + (l3 ? q3 : 0) * 64 + lane;
+      const float o0 = *p0, o1 = *p1, o2 = *p2, o3 = *p3;
+      if (l0) *p0 = o0 + g0;
+      if (l1) *p1 = o1 + g1;
+      if (l2) *p2 = o2 + g2;
+      if (l3) *p3 = o3 + g3;
+    }
+  }
+  __syncthreads();
+  f4 *dst = (f4 *)(part + ((size_t)blockIdx.x * gridDim.y + b) * ((size_t)2 * Q * 64) + ((size_t)tap * Q + qbase) * 64);
+  for (int i = lane; i < QP * 16; i += 64) dst[i] = ((const f4 *)tab)[i];
+}
+struct EmbedSlabOp64 {  // slab word (tap * Q + q, c) -> the (C, Q, 2) table
+  float *dcw;
+  int Q;
+  __device__ __forceinline__ float *dw(int m, int n) const {
+    const int tap = m >= Q ? 1 : 0, q = m - tap * Q;
+    return dcw + ((size_t)n * Q + q) * 2 + tap;
+  }
+};
+struct EmbedSlabOp {  // slab_reduce_kernel's view of the (C, Q, 2) table as rows of 64 words
+  float *dcw;
+  __device__ __forceinline__ float *dw(int m, int n) const { return dcw + (size_t)m * 64 + n; }
+};
 
 // softmax over channels, in place; one thread per (b, column)
 __global__ void softmax_kernel(float *__restrict__ y, int Q, int S) {
@@ -1248,10 +1361,35 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       set_error("mvn_backward: input_channels %d > 8192 not supported by the embedding gradient", Q);
       return MVN_ERR_UNSUPPORTED;
     }
+    const int chunks64 = (T + EG64_CHUNK - 1) / EG64_CHUNK;
+    if (C == 64 && Q % EG64_PARTS == 0 && (size_t)Q / EG64_PARTS * 64 * sizeof(float) <= 64 * 1024 && slab &&
+        (size_t)chunks64 * batch * 2 * Q * 64 <= slab_floats) {
+      const size_t lds = (size_t)Q / EG64_PARTS * 64 * sizeof(float) + EG64_CHUNK * sizeof(int);
+      rc = ensure_max_dynamic_lds((const void *)embed_grad64_kernel, "hipFuncSetAttribute(embed_grad64)");
+      if (rc) return rc;
+      hipLaunchKernelGGL(embed_grad64_kernel, dim3(chunks64, batch, 2 * EG64_PARTS), dim3(64), lds, s, index, index_stride,
+                         act_view(dxo_p, batch, C, g.Tp), Q, T, slab);
+      EmbedSlabOp64 eo;
+      eo.dcw = gr->causal_w; eo.Q = Q;
+      hipLaunchKernelGGL(slab_reduce_kernel<EmbedSlabOp64>, dim3((unsigned)(2 * Q * 64 / 32)), dim3(32 * RED_SEG), 0, s,
+                         eo, slab, chunks64 * batch, 2 * Q, 64);
+      return check_hip(hipGetLastError(), "mvn_backward");
+    }
     const int cg = std::max(1, std::min(C, 8192 / Q));
-    hipLaunchKernelGGL(embed_grad_kernel, dim3((T + EG_CHUNK - 1) / EG_CHUNK, (C + cg - 1) / cg, batch),
-                       dim3(256), (size_t)cg * Q * 2 * sizeof(float), s, gr->causal_w, index,
-                       index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T, cg);
+    const int chunks = (T + EG_CHUNK - 1) / EG_CHUNK;
+    // one table copy per (chunk, sequence) in the layer loop's slab scratch (idle by now), summed by
+    // slab_reduce_kernel; without room for them the workgroups add to the table with atomics
+    const size_t table = (size_t)C * Q * 2;
+    float *part = (table % 64 == 0 && slab && (size_t)chunks * batch * table <= slab_floats) ? slab : nullptr;
+    hipLaunchKernelGGL(embed_grad_kernel, dim3(chunks, (C + cg - 1) / cg, batch),
+                       dim3(1024), (size_t)cg * Q * 2 * sizeof(float), s, gr->causal_w, index,
+                       index_stride, act_view(dxo_p, batch, C, g.Tp), C, Q, T, cg, part);
+    if (part) {
+      EmbedSlabOp eo;
+      eo.dcw = gr->causal_w;
+      hipLaunchKernelGGL(slab_reduce_kernel<EmbedSlabOp>, dim3((unsigned)(table / 32)), dim3(32 * RED_SEG), 0, s, eo,
+                         part, chunks * batch, (int)(table / 64), 64);
+    }
   }
   return check_hip(hipGetLastError(), "mvn_backward");
 }
