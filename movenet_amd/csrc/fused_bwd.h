@@ -267,9 +267,22 @@ __global__ __launch_bounds__(32 * RED_SEG) void reduce_rs64_kernel(Op op, const 
 // `op` describes where the gradients go (WgRsOp::dw / db); slab: chunks * batch * 128 * 64 floats,
 // bias_scratch: chunks * batch * 128 floats.  False when the scratch is too small (the caller
 // then runs the two-kernel form).
+// The first half's reduction, left for the second half's launch to run together with its own: one
+// reduce launch per layer instead of two (each costs ~5 us, most of it fixed).  `slab_used` floats
+// at the front of the slab scratch stay occupied until then.
+template <class WgOp>
+struct PendingRsReduce {
+  bool on = false;
+  WgOp op;
+  const float *part = nullptr, *bias = nullptr;
+  int nparts = 0;
+  size_t slab_used = 0;
+};
+
 template <class WgOp>
 static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int batch, float *bias_scratch,
-                                 float *slab, size_t slab_floats, hipStream_t s) {
+                                 float *slab, size_t slab_floats, hipStream_t s,
+                                 PendingRsReduce<WgOp> *defer = nullptr) {
   const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return true;
   int chunks, chunk_t;
@@ -277,8 +290,23 @@ static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int bat
   const size_t need = (size_t)chunks * batch * 128 * 64;
   if (!bias_scratch || !slab || need > slab_floats) return false;
   hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, chunk_t, bias_scratch, slab);
-  hipLaunchKernelGGL(reduce_rs64_kernel<WgOp>, dim3(256 + 4), dim3(32 * RED_SEG), 0, s, op, slab, bias_scratch, chunks * batch);
+  if (defer) {
+    defer->on = true;
+    defer->op = op;
+    defer->part = slab;
+    defer->bias = bias_scratch;
+    defer->nparts = chunks * batch;
+    defer->slab_used = need;
+  } else {
+    hipLaunchKernelGGL(reduce_rs64_kernel<WgOp>, dim3(256 + 4), dim3(32 * RED_SEG), 0, s, op, slab, bias_scratch, chunks * batch);
+  }
   return true;
+}
+template <class WgOp>
+static void flush_pending_rs(PendingRsReduce<WgOp> &p, hipStream_t s) {
+  if (!p.on) return;
+  hipLaunchKernelGGL(reduce_rs64_kernel<WgOp>, dim3(256 + 4), dim3(32 * RED_SEG), 0, s, p.op, p.part, p.bias, p.nparts);
+  p.on = false;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -495,9 +523,37 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
 }
 
 // `op`: where the gradients go (WgFgOpT<false>::dw).  slab: chunks * batch * 128 * 128 floats.
-template <class WgOp>
+// both halves' reductions of a layer: workgroups [0, 260) as reduce_rs64_kernel, [260, 260 + 512) the
+// 128 x 128 filter/gate elements as slab_reduce_kernel
+template <class RsOp, class FgOp>
+__global__ __launch_bounds__(32 * RED_SEG) void reduce_layer64_kernel(RsOp rs, const float *__restrict__ rs_part,
+                                                                       const float *__restrict__ rs_bias, int n_rs, FgOp fg,
+                                                                       const float *__restrict__ fg_part, int n_fg) {
+  __shared__ float red[RED_SEG][32];
+  const int e = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const bool is_fg = blockIdx.x >= 260, is_bias = !is_fg && blockIdx.x >= 256;
+  const size_t stride = is_fg ? (size_t)128 * 128 : is_bias ? 128 : (size_t)128 * 64;
+  const size_t idx = (size_t)(blockIdx.x - (is_fg ? 260 : is_bias ? 256 : 0)) * 32 + e;
+  red[seg][e] = slab_segment_sum(is_fg ? fg_part : is_bias ? rs_bias : rs_part, stride, idx, is_fg ? n_fg : n_rs, seg);
+  __syncthreads();
+  if (seg == 0) {
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < RED_SEG; ++k) t += red[k][e];
+    float *dst = is_fg ? fg.dw((int)(idx >> 7), (int)(idx & 127))
+                       : is_bias ? rs.db((int)idx) : rs.dw((int)(idx >> 6), (int)(idx & 63));
+    if (dst) *dst += t;
+  }
+}
+
+template <class WgOp, class RsOp>
 static int launch_bwd_dx_wgfg64(const FusedBwdBArgs &a, const WgOp &op, int batch, float *slab,
-                                size_t slab_floats, hipStream_t s, bool *done) {
+                                size_t slab_floats, hipStream_t s, bool *done, PendingRsReduce<RsOp> *pend) {
+  if (pend && pend->on) {  // the first half's slabs sit at the front of the scratch until they are reduced
+    if (pend->slab_used > slab_floats) return MVN_OK;
+    slab += pend->slab_used;
+    slab_floats -= pend->slab_used;
+  }
   *done = false;
   const int nt = a.t_end - (a.t_out0 & ~TILE_ALIGN);
   if (a.t_end <= a.t_out0 || batch <= 0) {
@@ -513,7 +569,13 @@ static int launch_bwd_dx_wgfg64(const FusedBwdBArgs &a, const WgOp &op, int batc
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_dx_wgfg64_kernel, dim3(chunks * batch), dim3(512), FBB_LDS_FLOATS * sizeof(float), s, a,
                      chunks, chunk_t, slab);
-  hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 128 / 32), dim3(32 * RED_SEG), 0, s, op, slab, chunks * batch, 128, 128);
+  if (pend && pend->on) {
+    hipLaunchKernelGGL((reduce_layer64_kernel<RsOp, WgOp>), dim3(260 + 128 * 128 / 32), dim3(32 * RED_SEG), 0, s, pend->op,
+                       pend->part, pend->bias, pend->nparts, op, slab, chunks * batch);
+    pend->on = false;
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel<WgOp>, dim3(128 * 128 / 32), dim3(32 * RED_SEG), 0, s, op, slab, chunks * batch, 128, 128);
+  }
   *done = true;
   return MVN_OK;
 }

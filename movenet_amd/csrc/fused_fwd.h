@@ -405,34 +405,13 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     }
   }
 
-  // A strip's x' and skip sums are HELD in registers and leave after the first product of the NEXT
-  // strip.  A load is only complete when every older store has been acknowledged (one in-order
-  // counter on gfx9), and a counter value above 63 cannot be waited for: with the 64 stores at the end of a
-  // strip the compiler's wait in front of the next strip's first use of a prefetched x(t) was
-  // vmcnt(0) -- a full store round trip per strip with the matrix cores idle.  Now every wait is
-  // >= 128 MFMAs behind the stores it covers.  Lanes that must not store (columns outside
-  // [t_begin, te), no output tensor) carry an offset beyond the buffer's num_records: the
-  // hardware drops the access, no exec-mask branch per store.
+  // Lanes that must not store (columns outside [t_begin, te), no output tensor) carry an offset
+  // beyond the buffer's num_records: the hardware drops the access -- no exec-mask branch per store.
+  // (Tried: holding a strip's x' and skip sums in registers until after the next strip's first
+  // product, so that no wait on a prefetched load sits right behind 64 fresh stores -- on gfx9 loads
+  // and stores retire through one in-order counter and the compiler's wait at the loop edge was
+  // vmcnt(0).  Measured 131.4 against 131.9 us per layer: the second wave of the SIMD covers it.)
   constexpr int FS_OOB = (int)0x80000000;
-  float hx[32], hk[32];
-  int hoxo = FS_OOB, hosk = FS_OOB;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) hx[j] = hk[j] = 0.f;
-  auto flush_held = [&]() {
-    FS_FENCE(xold4);
-    FS_FENCE(skld4);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hx[16 * h + r]), xob, hoxo, (32 * h + (r & 3) + 8 * (r >> 2)) * xold4, 0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hk[16 * h + r]), skb, hosk, (32 * h + (r & 3) + 8 * (r >> 2)) * skld4, 0);
-  };
-
   for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
     const int t = t0 + li;
     bool live;
@@ -497,8 +476,6 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
           acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(
               aw[blk][e], k4 >= 16 ? xn1[4 * (k4 - 16) + e] : k4 >= 8 ? xb1[4 * (k4 - 8) + e] : xa0[4 * k4 + e], acc[blk], 0, 0, 0);
     }
-    if (!HAS_CTX) flush_held();  // the previous strip's x' and skip sums (the conditioned variant has no
-                                 // look-ahead to protect and no register to hold them: it stores at once)
     // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
     float z[32];
     FS_FENCE(thld4);
@@ -567,25 +544,33 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
           acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[blk][e], z[4 * k4 + e], acc[blk], 0, 0, 0);
     }
     // ---- x' = (y + br) + x(t): x(t) of this lane's channel is input register 32 + 16 h + r;
-    // skip (+)= y + bs, columns t - t_base, live from skip_lo.  Both are held (see above).
+    // skip (+)= y + bs, columns t - t_base, live from skip_lo
+    FS_FENCE(xold4);
+    FS_FENCE(skld4);
+    {
+      const int oxo_m = (has_out && live) ? oxo : FS_OOB, osk_m = skip_live ? osk : FS_OOB;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
-        hx[16 * h + r] = (acc[h][r] + BI[c0 + cbase]) + xb1[16 * h + r];
-        const float v = acc[2 + h][r] + BI[64 + c0 + cbase];
-        hk[16 * h + r] = a.first_layer ? v : xa0[16 * h + r] + v;
-      }
-    hoxo = (has_out && live) ? oxo : FS_OOB;
-    hosk = skip_live ? osk : FS_OOB;
-    if (HAS_CTX) flush_held();
+        for (int r = 0; r < 16; ++r) {
+          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[h][r] + BI[c0 + cbase]) + xb1[16 * h + r]), xob, oxo_m,
+                                                c0 * xold4, 0);
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          const float v = acc[2 + h][r] + BI[64 + k0 + cbase];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a.first_layer ? v : xa0[16 * h + r] + v), skb, osk_m, k0 * skld4, 0);
+        }
+    }
     if (!HAS_CTX) {
 #pragma unroll
       for (int j = 0; j < 32; ++j) xb1[j] = xn1[j];
     }
   }
-  if (!HAS_CTX) flush_held();
 }
 
 static int launch_fused_layer64s(const FusedFwdPArgs &a, int batch, hipStream_t s) {

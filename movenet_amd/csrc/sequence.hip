@@ -1274,6 +1274,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l];
     wr.dbs = gr->skip_b[l];
     bool fused_a = false;
+    PendingRsReduce<WgRsOp> pend;
     if (fused_bwd && C == 64 && Kc == 64 && bias_scratch2) {
       // dz and the residual/skip weight gradients from ONE pass over dxo, dskip, tanh, sigmoid
       // (fused_bwd.h; conditioned layers too: nothing here touches the context); on the main
@@ -1282,7 +1283,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       fa.t_begin = t_lo; fa.t_end = T; fa.t_skip0 = t_skip0; fa.t_base = g.t_base;
       fa.wr = p->residual_w[l]; fa.ws = p->skip_w[l];
       fa.dxo = dxo; fa.dskip = dskip; fa.th = th; fa.sg = sg; fa.dfg = dfg;
-      fused_a = launch_bwd_dz_wgrs64(fa, wr, batch, bias_scratch2, slab, slab_floats, s);
+      // (all_fused: its reduction runs in the second half's reduce launch)
+      fused_a = launch_bwd_dz_wgrs64(fa, wr, batch, bias_scratch2, slab, slab_floats, s, all_fused ? &pend : nullptr);
     }
     if (!fused_a) {
       if (bias_scratch2)
@@ -1311,9 +1313,10 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
       wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
       wf.dwcf = nullptr; wf.dwcg = nullptr; wf.dbcf = nullptr; wf.dbcg = nullptr;
-      rc = launch_bwd_dx_wgfg64(fb, wf, batch, slab, slab_floats, s, &fused_b);
+      rc = launch_bwd_dx_wgfg64(fb, wf, batch, slab, slab_floats, s, &fused_b, &pend);
       if (rc) return rc;
     }
+    flush_pending_rs(pend, s);  // (only if the second half did not take it along)
     await(1, s2);
     auto run_wf = [&](auto wf) {
       wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
