@@ -54,6 +54,9 @@ static void fb_chunks(int nt, int batch, int per_cu, int *chunks, int *chunk_t, 
   *chunk_t = chunk_tiles * tile;
 }
 
+#ifndef MVN_EXP
+#define MVN_EXP 0  // timing builds of the first half (wrong results): 51 no dfg stores, 52 no global loads after a
+#endif             // workgroup's first tile, 53 both
 __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, int chunks_per_b, int chunk_t,
                                                               float *__restrict__ bias_part,
                                                               float *__restrict__ part) {
@@ -155,7 +158,11 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
   __syncthreads();
   for (int t0 = tb; t0 < te; t0 += TT) {
     const bool more = t0 + TT < te;
+#if MVN_EXP == 52 || MVN_EXP == 53
+    if (more && a.t_end < 0) gload(t0 + TT);
+#else
     if (more) gload(t0 + TT);  // the next tile's loads fly under this tile's MFMAs
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // ---- dz' (32 t x 32 c) = sum over the 128 rows of the tile
     f32x16 accd;
@@ -205,6 +212,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
       // whole-row float4 stores: rows 16 p + srow, columns t0 + st .. +3, inside [t_begin, te)
       const int t = t0 + st;
       float *base = a.dfg.p + (size_t)b * a.dfg.sb + t;
+#if MVN_EXP == 51 || MVN_EXP == 53
+      if (a.t_end >= 0) {
+      } else
+#endif
       if (t >= a.t_begin && t + 3 < te) {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
