@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
             if (t + e >= a.t_begin && t + e < te) base[(size_t)(16 * p + srow) * a.dfg.ld + e] = As[16 * p + srow][st + e];
       }
     }
-    __syncthreads();
+    // (no barrier here: a thread's lstore() overwrites exactly the staging elements the same thread
+    // has just read for its global stores, and Th / Sg were last read before the barrier above)
     if (more) {
       lstore();
       __syncthreads();
