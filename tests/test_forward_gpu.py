@@ -269,6 +269,44 @@ def test_fused_backward_kernels_match_two_kernel_forms_and_oracle(monkeypatch, l
                 assert rel_err(g, params[k].grad) < 3e-4, k
 
 
+@pytest.mark.parametrize("pattern", ["constant", "runs", "pairs"])
+def test_embedding_gradient_with_repeated_classes(pattern):
+    """The C = 64 embedding gradient (embed_grad64_kernel) keeps four time steps in flight per wave and
+    merges equal classes among them before its read-modify-write of the LDS table: inputs whose
+    neighbouring samples repeat a class are the case random indices hardly ever produce.  The
+    length crosses a 1024-step chunk and is no multiple of 4; checked against autograd on the
+    oracle (movenet/modules.py CausalConv1d, the first op of WaveNet.forward)."""
+    from oracle import wavenet_oracle as O
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=3, stack_size=1, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=9, gain=1.5)
+    dims = O.Dims(**cfg)
+    t_len, batch = 1024 + 131, 2
+    t = torch.arange(t_len)
+    if pattern == "constant":
+        idx = torch.full((batch, t_len), 7, dtype=torch.int64)
+    elif pattern == "runs":      # runs of 1..6 equal samples, a different class per run
+        run = torch.cumsum((torch.arange(t_len) % 7 == 0).long(), 0)
+        idx = torch.stack([(run * 37) % 256, (run * 91 + 5) % 256])
+    else:                        # a b a b ...: equal classes two steps apart
+        idx = torch.stack([torch.where(t % 2 == 0, 3, 200), torch.where(t % 2 == 0, 255, 0)])
+    x = one_hot(idx, 256)
+    w = torch.linspace(0.5, 1.5, 256).view(1, 256, 1)
+    m = _model(cfg, sd).train()
+    out = m(x.to(DEV), output_unnormalized=False)
+    (out * w.to(DEV)).square().mean().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_o = O.forward(params, dims, x, output_unnormalized=False)
+    (out_o * w).square().mean().backward()
+    got = dict(m.named_parameters())["causal_conv.conv.weight"].grad.cpu()
+    want = params["causal_conv.conv.weight"].grad
+    assert rel_err(got, want) < 3e-4
+    # classes that never occur get exactly zero
+    never = torch.ones(256, dtype=torch.bool)
+    never[idx.unique()] = False
+    assert torch.all(got[:, never, :] == 0)
+
+
 @pytest.mark.parametrize("layers,t_len,batch", [((3, 2), 100, 3), ((10, 1), 1024 + 700 + 37, 2), ((6, 2), 64 * 9 + 1, 17)])
 def test_persistent_forward_kernel_matches_per_tile_kernel_and_oracle(monkeypatch, layers, t_len, batch):
     """C = K = 64 takes the persistent forward layer kernel (csrc/fused_fwd.h); the per-tile
