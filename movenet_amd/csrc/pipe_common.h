@@ -409,11 +409,18 @@ __device__ __forceinline__ int choose_class(const float (&lg)[4], float temperat
   int pick;
   if (temperature > 0.f) {
     const float lsum = (p[0] + p[1]) + (p[2] + p[3]);
-    float incl = lsum;  // inclusive scan of lane totals, class order
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float n = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += n;
+    // inclusive scan of the lane totals in class order: four DPP row shifts inside each row of 16
+    // lanes (zeros shifted in), then the totals of the rows below as scalars (six __shfl_up steps
+    // = six LDS-crossbar round trips before: ~0.25 us of every sampled step)
+    float incl = lsum;
+    incl += dpp_mov<0x111>(incl);  // row_shr:1
+    incl += dpp_mov<0x112>(incl);  // row_shr:2
+    incl += dpp_mov<0x114>(incl);  // row_shr:4
+    incl += dpp_mov<0x118>(incl);  // row_shr:8
+    {
+      const float r0 = lane_value(incl, 15), r1 = lane_value(incl, 31), r2 = lane_value(incl, 47);
+      const int row = lane >> 4;
+      incl += row == 0 ? 0.f : row == 1 ? r0 : row == 2 ? r0 + r1 : (r0 + r1) + r2;
     }
     const float total = lane_value(incl, 63);
     const float target = philox_uniform(seed, u, b) * total;
