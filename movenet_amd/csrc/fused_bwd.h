@@ -415,12 +415,10 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     asm volatile("" : "+v"(srow_q));
     const int t = t0 + st;
     const int hi = min(a.t_end, te);
+    // (the two validity ranges one after the other, with a scheduling fence in between: with both
+    // sets of lane masks live at once this cold path spilled two registers)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      areg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi);
-      // dfg[u + d] for the outputs u of this tile: u < te, u + d < T
-      a2reg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0) + a.d, t, a.t_lo - a.d, min(a.t_end - a.d, te));
-    }
+    for (int p = 0; p < 4; ++p) areg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = 32 * p + srow_q;
@@ -429,6 +427,11 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
 #pragma unroll
     for (int p = 0; p < 2; ++p)
       oreg[p] = has_dxo ? ld4_edge(a.dxo.at(b, 32 * p + srow_q, 0), t, a.t_lo, hi) : kZero4;
+    __builtin_amdgcn_sched_barrier(0);
+    // dfg[u + d] for the outputs u of this tile: u < te, u + d < T
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      a2reg[p] = ld4_edge(a.dfg.at(b, 32 * p + srow_q, 0) + a.d, t, a.t_lo - a.d, min(a.t_end - a.d, te));
   };
   auto gload = [&](int t0) {
     if (interior(t0)) {
@@ -525,13 +528,20 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     __syncthreads();  // the next tile is staged; the staging tile has been read
   }
   // ---- this workgroup's slab (wgrad2_kernel's format, 128 x 128)
+  {
+    // (indices re-derived from the thread id behind a fence: kept live across the tile loop they
+    // were the two registers the kernel spilled)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, wm_e = wave_e >> 1, wn_e = wave_e & 1;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = 32 * wm + acc_row(r, lane), n = 64 * wn + 32 * ni + li;
-      part[((size_t)blockIdx.x * 128 + m) * 128 + n] = accw[ni][r];
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * wm_e + acc_row(r, lane_e), n = 64 * wn_e + 32 * ni + (lane_e & 31);
+        part[((size_t)blockIdx.x * 128 + m) * 128 + n] = accw[ni][r];
+      }
+  }
 }
 
 // `op`: where the gradients go (WgFgOpT<false>::dw).  slab: chunks * batch * 128 * 128 floats.

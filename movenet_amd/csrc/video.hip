@@ -93,7 +93,10 @@ struct UpOp {
   __device__ __forceinline__ void one(int b, int m, int t, float v) const {
     if (m >= kUp * C) return;
     const int co = m / kUp, j = m - co * kUp;
-    *out.at(b, co, kUp * t + j) = v + bias[co];
+    // (one 32-bit offset from the sequence's base: as 64-bit pointers the 32 addresses of an
+    // epilogue took 64 registers and the kernel spilled 66; 5 are left)
+    float *base = out.at(b, 0, 0);
+    base[(unsigned)(co * out.ld + kUp * t + j)] = v + bias[(unsigned)co];
   }
   __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
                                            const f32x16 &a1) const {
@@ -101,6 +104,7 @@ struct UpOp {
     for (int r = 0; r < 16; ++r) {
       one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
       one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
+      asm volatile("" ::: "memory");  // (keeps the 32 bias loads from being gathered in front of the stores)
     }
   }
 };
