@@ -90,22 +90,24 @@ struct UpOp {
   __device__ __forceinline__ float x(int b, int k, int t) const {
     return (k < C && t < t_end) ? *xin.at(b, k, t) : 0.f;
   }
-  __device__ __forceinline__ void one(int b, int m, int t, float v) const {
-    if (m >= kUp * C) return;
-    const int co = m / kUp, j = m - co * kUp;
-    // (one 32-bit offset from the sequence's base: as 64-bit pointers the 32 addresses of an
-    // epilogue took 64 registers and the kernel spilled 66; 5 are left)
-    float *base = out.at(b, 0, 0);
-    base[(unsigned)(co * out.ld + kUp * t + j)] = v + bias[(unsigned)co];
-  }
   __device__ __forceinline__ void epilogue(int b, int mb, int t, int lane, const f32x16 &a0,
                                            const f32x16 &a1) const {
+    // row m = U + 4 (lane >> 5) with U = 64 mb + 32 half + (r & 3) + 8 (r >> 2) uniform: the two
+    // divisions by 10 per output run on the scalar unit, a lane only selects (as per-lane divisions
+    // plus 64-bit addresses the 32 outputs of an epilogue spilled 66 registers)
+    float *base = out.at(b, 0, 0);
+    const bool hi = lane >= 32;
+    const unsigned tcol = (unsigned)(kUp * t);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      one(b, mb * 64 + acc_row(r, lane), t, a0[r]);
-      one(b, mb * 64 + 32 + acc_row(r, lane), t, a1[r]);
-      asm volatile("" ::: "memory");  // (keeps the 32 bias loads from being gathered in front of the stores)
-    }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int U = mb * 64 + 32 * half + (r & 3) + 8 * (r >> 2);
+        const int co_a = U / kUp, j_a = U - co_a * kUp, co_b = (U + 4) / kUp, j_b = (U + 4) - co_b * kUp;
+        const int co = hi ? co_b : co_a, j = hi ? j_b : j_a;
+        if (U + (hi ? 4 : 0) < kUp * C)
+          base[(unsigned)(co * out.ld + j) + tcol] = (half ? a1[r] : a0[r]) + bias[(unsigned)co];
+      }
   }
 };
 
