@@ -54,6 +54,25 @@ static void fb_chunks(int nt, int batch, int per_cu, int *chunks, int *chunk_t, 
   *chunk_t = chunk_tiles * tile;
 }
 
+// 16-byte raw buffer accesses: (resource of a tensor and sequence) + (per-lane byte offset, formed
+// once per workgroup) + (scalar byte offset of the row block and tile).  As 64-bit pointers the
+// 14 loads of a tile cost ~100 vector instructions of address arithmetic (v_mad_i64_i32,
+// v_lshl_add_u64), which in fp32 come straight out of the matrix cores' time.
+constexpr int FB_RSRC = 0x00020000;  // raw buffer, 32-bit data format (gfx9)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fb_rsrc(const float *p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0x7FFFFFFF, FB_RSRC);
+}
+__device__ __forceinline__ f4 fb_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ void fb_store16(f4 x, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)},
+                                         r, voff, soff, 0);
+}
+
 #ifndef MVN_EXP
 #define MVN_EXP 0  // timing builds of the first half (wrong results): 51 no dfg stores, 52 no global loads after a
 #endif             // workgroup's first tile, 53 both
@@ -96,6 +115,13 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
 #pragma unroll
   for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
   unsigned azero = 0;
+  const __amdgpu_buffer_rsrc_t dxob = fb_rsrc(a.dxo.p + (size_t)b * a.dxo.sb);
+  const __amdgpu_buffer_rsrc_t dskb = fb_rsrc(a.dskip.p + (size_t)b * a.dskip.sb);
+  const __amdgpu_buffer_rsrc_t thb = fb_rsrc(a.th.p + (size_t)b * a.th.sb);
+  const __amdgpu_buffer_rsrc_t sgb = fb_rsrc(a.sg.p + (size_t)b * a.sg.sb);
+  const __amdgpu_buffer_rsrc_t dfgb = fb_rsrc(a.dfg.p + (size_t)b * a.dfg.sb);
+  const int vo_dxo = 4 * (srow * a.dxo.ld + st), vo_dsk = 4 * (srow * a.dskip.ld + st);
+  const int vo_th = 4 * (srow * a.th.ld + st), vo_sg = 4 * (srow * a.sg.ld + st), vo_dfg = 4 * (srow * a.dfg.ld + st);
   auto gload = [&](int t0) {
     int srow_q = srow;
     asm volatile("" : "+v"(srow_q));
@@ -108,19 +134,25 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
     const bool s_full = t0 >= skip_lo && t0 + TT <= te, s_none = t0 + TT <= skip_lo;
     azero = (has_dxo ? 0u : 0x0Fu) | (s_none ? 0xF0u : 0u);
     if (x_full && (s_full || s_none)) {
-      const float *t0p = a.th.at(b, srow_q, 0) + t;
+      // raw buffer loads (fb_load16): per-lane offset of (row srow, column st) + scalar offset of the
+      // row block and the tile
+      int ld_dxo = 4 * a.dxo.ld, ld_dsk = 4 * a.dskip.ld, ld_th = 4 * a.th.ld, ld_sg = 4 * a.sg.ld;
+      asm volatile("" : "+s"(ld_dxo), "+s"(ld_dsk), "+s"(ld_th), "+s"(ld_sg));
+      const int c4 = 4 * t0;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const float *q = ((azero >> p) & 1u) ? t0p
-                         : p < 4           ? a.dxo.at(b, 16 * p + srow_q, 0) + t
-                                           : a.dskip.at(b, 16 * (p - 4) + srow_q, 0) + (t - a.t_base);
-        areg[p] = ldg4(q);
+        if ((azero >> p) & 1u)
+          areg[p] = fb_load16(thb, vo_th, c4);
+        else if (p < 4)
+          areg[p] = fb_load16(dxob, vo_dxo, 16 * p * ld_dxo + c4);
+        else
+          areg[p] = fb_load16(dskb, vo_dsk, 16 * (p - 4) * ld_dsk + c4 - 4 * a.t_base);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        treg[p] = ldg4(a.th.at(b, 16 * p + srow_q, 0) + t);
-        sreg[p] = ldg4(a.sg.at(b, 16 * p + srow_q, 0) + t);
+        treg[p] = fb_load16(thb, vo_th, 16 * p * ld_th + c4);
+        sreg[p] = fb_load16(sgb, vo_sg, 16 * p * ld_sg + c4);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -219,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
       if (t >= a.t_begin && t + 3 < te) {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
-          *(f4 *)(base + (size_t)(16 * p + srow) * a.dfg.ld) = *(const f4 *)&As[16 * p + srow][st];
+          fb_store16(*(const f4 *)&As[16 * p + srow][st], dfgb, vo_dfg, 4 * (16 * p * a.dfg.ld + t0));
       } else {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
@@ -388,23 +420,28 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   // queue while the older one ran its MFMAs alone, and then ran its own alone behind it --
   // the two waves of a SIMD took turns on the matrix core (in-kernel timers: 24 k cycles per
   // tile against 16 k of MFMAs).
+  // (interior tiles: raw buffer loads, see fb_load16; the per-lane offsets cover row srow and column st)
+  const __amdgpu_buffer_rsrc_t dfgb = fb_rsrc(a.dfg.p + (size_t)b * a.dfg.sb);
+  const __amdgpu_buffer_rsrc_t xinb = fb_rsrc(a.xin.p + (size_t)b * a.xin.sb);
+  const __amdgpu_buffer_rsrc_t dxob = fb_rsrc(a.dxo.p + (size_t)b * a.dxo.sb);
+  const __amdgpu_buffer_rsrc_t dxib = fb_rsrc(a.dxi.p + (size_t)b * a.dxi.sb);
+  const int vo_dfg = 4 * (srow * a.dfg.ld + st), vo_xin = 4 * (srow * a.xin.ld + st);
+  const int vo_dxo = 4 * (srow * a.dxo.ld + st), vo_dxi = 4 * (srow * a.dxi.ld + st);
   auto gload_part = [&](int t0, int part) {
-    int srow_q = srow;
-    asm volatile("" : "+v"(srow_q));
-    const int t = t0 + st;
+    int ld_dfg = 4 * a.dfg.ld, ld_xin = 4 * a.xin.ld, ld_dxo = 4 * a.dxo.ld;
+    asm volatile("" : "+s"(ld_dfg), "+s"(ld_xin), "+s"(ld_dxo));  // (row-block offsets formed here, not hoisted)
+    const int c4 = 4 * t0;
     if (part < 4) {
-      areg[part] = ldg4(a.dfg.at(b, 32 * part + srow_q, 0) + t);
-      a2reg[part] = ldg4(a.dfg.at(b, 32 * part + srow_q, 0) + t + a.d);
+      areg[part] = fb_load16(dfgb, vo_dfg, 32 * part * ld_dfg + c4);
+      a2reg[part] = fb_load16(dfgb, vo_dfg, 32 * part * ld_dfg + c4 + 4 * a.d);
     } else if (part < 6) {
 #pragma unroll
-      for (int p = 2 * (part - 4); p < 2 * (part - 4) + 2; ++p) {
-        const int row = 32 * p + srow_q;  // rows [0, 64): x(t - d); [64, 128): x(t)
-        xreg[p] = ldg4(a.xin.at(b, row & (C - 1), 0) + t - (p < 2 ? a.d : 0));
-      }
+      for (int p = 2 * (part - 4); p < 2 * (part - 4) + 2; ++p)  // rows [0, 64): x(t - d); [64, 128): x(t)
+        xreg[p] = fb_load16(xinb, vo_xin, ((32 * p) & (C - 1)) * ld_xin + c4 - (p < 2 ? 4 * a.d : 0));
     } else if (part == 6) {
       if (has_dxo) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) oreg[p] = ldg4(a.dxo.at(b, 32 * p + srow_q, 0) + t);
+        for (int p = 0; p < 2; ++p) oreg[p] = fb_load16(dxob, vo_dxo, 32 * p * ld_dxo + c4);
       } else {
         oreg[0] = oreg[1] = kZero4;
       }
@@ -512,7 +549,7 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
         const f4 r = f4{(v1.x + v0.x) + o.x, (v1.y + v0.y) + o.y, (v1.z + v0.z) + o.z, (v1.w + v0.w) + o.w};
         float *q = base + (size_t)row * a.dxi.ld;
         if (t >= a.t_out0 && t + 3 < te) {
-          *(f4 *)q = r;
+          fb_store16(r, dxib, vo_dxi, 4 * (32 * p * a.dxi.ld + t0));
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
