@@ -16,8 +16,11 @@
 //     k-steps per ds_read_b128), z formed on the fly from the tanh and sigmoid tiles;
 //   * the gate derivative in registers (a lane holds 4 x 4 consecutive t of one channel), df | dg
 //     through the staging tile as whole-row float4 stores.
-// Per-workgroup partial tiles and bias sums leave in wgrad2's slab format: the same
-// slab_reduce_kernel / bias_reduce_kernel finish the job (fixed order: deterministic).
+// Per-workgroup partial tiles and bias sums leave in wgrad2's slab format and are summed in a fixed
+// order (deterministic): reduce_layer64_kernel adds up both halves' slabs of a layer in one launch
+// behind the second half (reduce_rs64_kernel when the second half runs in its generic form).
+// Tiles start at multiples of 32 columns (TILE_ALIGN); interior tiles use raw buffer accesses
+// (fb_load16 / fb_store16: no 64-bit address arithmetic per access).
 #pragma once
 #include "common.h"
 #include "gemm_family.h"
