@@ -86,6 +86,38 @@ def test_greedy_free_running_indices_bit_exact(golden, name):
         assert np.array_equal(g2.samples.cpu().numpy(), fx["indices"])
 
 
+@pytest.mark.parametrize("bias", ["all_equal", "two_tied", "clear_winner"])
+def test_greedy_ties_take_the_first_maximum(bias):
+    """Greedy decoding returns the FIRST arg-max of softmax(softmax(logits)) (movenet/wavenet.py:227-233,
+    torch.argmax).  The pipelined heads pick by one (value, index, runner-up) reduction when the top logit
+    leads by >= 1e-3 and run the full double softmax otherwise: with the head's last conv zeroed the logits
+    are its bias, so exact ties (all classes equal; two classes sharing the maximum) exercise the
+    second form and a clear winner the first, on every variant."""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=3)
+    sd["dense_conv.conv2.weight"] = torch.zeros_like(sd["dense_conv.conv2.weight"])
+    b = torch.zeros(256)
+    if bias == "two_tied":
+        b[9] = b[200] = 1.25
+        want = 9
+    elif bias == "clear_winner":
+        b[9], b[200] = 1.25, 1.5
+        want = 200
+    else:
+        want = 0
+    sd["dense_conv.conv2.bias"] = b
+    rf = O.Dims(**cfg).receptive_fields
+    pidx = synthetic_indices(2, rf, 256, 11)
+    for variant in _variants(cfg):
+        g = _gen(cfg, sd, 2, rf + 40, variant=variant)
+        g.prime(pidx.to(DEV))
+        g.advance(40)
+        g.check_errors()
+        got = g.samples[:, rf:].cpu().numpy()
+        assert np.all(got == want), (variant, bias, np.unique(got))
+
+
 def test_model_api_generate_matches_reference(golden):
     """WaveNet.generate on one-hot input == the reference's one-hot output."""
     from movenet_amd.wavenet import WaveNet
