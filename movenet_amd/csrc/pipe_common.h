@@ -426,20 +426,22 @@ __device__ __forceinline__ int choose_class(const float (&lg)[4], float temperat
     const float target = philox_uniform(seed, u, b) * total;
     const float cdf = incl - lsum;
     int cand = Q - 1;
+    bool hit = false;
 #pragma unroll
     for (int k = 3; k >= 0; --k) {
       // walk down so that the smallest qualifying class wins
       const float c_k = cdf + (k == 0 ? p[0] : k == 1 ? p[0] + p[1]
                                               : k == 2 ? (p[0] + p[1]) + p[2]
                                                        : ((p[0] + p[1]) + p[2]) + p[3]);
-      if (c_k > target) cand = 4 * lane + k;
+      if (c_k > target) {
+        cand = 4 * lane + k;
+        hit = true;
+      }
     }
-    cand = min(cand, dpp_movi<DPP_XOR1>(cand));
-    cand = min(cand, dpp_movi<DPP_XOR2>(cand));
-    cand = min(cand, dpp_movi<DPP_HALF_MIRROR>(cand));
-    cand = min(cand, dpp_movi<DPP_MIRROR>(cand));
-    pick = min(min(__builtin_amdgcn_readlane(cand, 0), __builtin_amdgcn_readlane(cand, 16)),
-               min(__builtin_amdgcn_readlane(cand, 32), __builtin_amdgcn_readlane(cand, 48)));
+    // the smallest qualifying class over the wave = the candidate of the FIRST lane that has one
+    // (classes ascend with the lane): one ballot and one readlane instead of a min-reduction
+    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(hit);
+    pick = lanes ? __builtin_amdgcn_readlane(cand, __builtin_ctzll(lanes)) : Q - 1;
   } else {
     float bv = p[0];
     int bi = 4 * lane;
