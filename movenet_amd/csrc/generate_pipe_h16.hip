@@ -359,6 +359,13 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
       const bool do_head = u < a.n_total && (u >= a.n_given || want_out);  // block-uniform
       int next_idx = 0;
+      // this step's Philox uniform, formed while the step's input is still on its way (the fence
+      // keeps it from being sunk to its use behind the head's barriers)
+      float uni = 0.f;
+      if (wave == 0 && a.temperature > 0.f) {
+        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b);
+        asm volatile("" : "+v"(uni));
+      }
       if (wave == 0) {
         if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
         float v[GL];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           const float lg[4] = {lv.x, lv.y, lv.z, lv.w};
           if (a.logits_out && u >= a.logits_t0)
             ((f4 *)(a.logits_out + ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
-          const int pick = choose_class(lg, a.temperature, a.seed, (uint32_t)u, (uint32_t)b, lane, Q);
+          const int pick = choose_class(lg, a.temperature, uni, lane, Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
           idx_cur = next_idx;
