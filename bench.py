@@ -45,9 +45,9 @@ PMC_TRAFFIC = {
     3: {"bytes_per_step_seq": (19818.3 + 15008.8) * 1024 / (16 * 16000),
         "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19818 KiB + WRITE_SIZE "
                   "15009 KiB per 16000-step launch of 16 sequences)"},
-    5: {"bytes_per_step_seq": (26326.1 + 18830.5) * 1024 / (16 * 16000),
-        "source": "profiles/r02_pmc_summary.json (gen_fold_kernel: FETCH_SIZE 26326 KiB + WRITE_SIZE "
-                  "18831 KiB per 16000-step launch of 16 sequences)"},
+    5: {"bytes_per_step_seq": (26321.9 + 17943.8) * 1024 / (16 * 16000),
+        "source": "profiles/r02_pmc_summary.json (gen_fold_kernel: FETCH_SIZE 26322 KiB + WRITE_SIZE "
+                  "17944 KiB per 16000-step launch of 16 sequences)"},
 }
 
 
