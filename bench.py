@@ -164,51 +164,115 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
     }
 
 
-def train_leg(dev, world, rank, steps=6, warmup=5, batch=16, t_len=16000):
+def dilations(cfg):
+    return [1 << i for _ in range(cfg["stack_size"]) for i in range(cfg["layer_size"])]
+
+
+def train_flop_per_step(cfg, batch: int, t_len: int, frames: int = 0) -> float:
+    """forward MACs per sequence = sum_l 5C^2 T_l + L C K S + (KQ + Q^2) S
+    (skip only where kept, causal conv as a gather), T_l = T - sum_{j<=l} d_j; with conditioning
+    (frames > 0) + 2C^2 T_l per layer, the Conv3d encoder (F x 4096 x C) and the three stride-10
+    transposed convs (C^2 per output sample: 10F + 100F + 1000F of them).  Step FLOP =
+    2 x 3 x batch x that (forward + both gradients)."""
+    C, K, Q = cfg["residual_channels"], cfg["skip_channels"], cfg["input_channels"]
+    ds = dilations(cfg)
+    rf = sum(ds) + cfg["stack_size"]
+    S = t_len - rf + 1
+    per_pos = (7 if frames else 5) * C * C
+    macs, a = 0, 0
+    for d in ds:
+        a += d
+        macs += per_pos * (t_len - a)
+    macs += len(ds) * C * K * S + (K * Q + Q * Q) * S
+    if frames:
+        macs += frames * 4096 * C + C * C * 1110 * frames
+    return 2.0 * 3.0 * batch * macs
+
+
+class clip_frames:
+    """the reference fixes the clip length through module constants (160 frames <->
+    160000 samples, wavenet.py:27-31).  BASELINE configs[2]/[3] use 32-frame clips: the
+    constants are set for the duration of the leg and restored."""
+
+    def __init__(self, frames):
+        self.frames = frames
+
+    def __enter__(self):
+        import movenet_amd.wavenet as W
+        self.saved = (W.MAX_VIDEO_FRAMES, W.MAX_AUDIO_FRAMES)
+        W.MAX_VIDEO_FRAMES, W.MAX_AUDIO_FRAMES = self.frames, 1000 * self.frames
+
+    def __exit__(self, *exc):
+        import movenet_amd.wavenet as W
+        W.MAX_VIDEO_FRAMES, W.MAX_AUDIO_FRAMES = self.saved
+
+
+TRAIN_WORKLOADS = {
+    # BASELINE configs[1]: audio only, 16 clips of 1 s per GPU
+    2: dict(batch=16, t_len=16000, frames=0,
+            name="BASELINE configs[1]: 30-layer WaveNet, Q=256, C=K=64, audio only, 16 clips x 16000 samples per GPU"),
+    # BASELINE configs[2] per GPU == configs[3] (batch 64 over 8 GPUs): video-conditioned, 8 clips of 32 frames
+    3: dict(batch=8, t_len=32000, frames=32,
+            name="BASELINE configs[2] (= configs[3] per GPU): config 2 + video conditioning, 32-frame clips "
+                 "(T=32000), 8 clips per GPU"),
+}
+
+
+def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
+    """Secondary metric M2 (BASELINE.json): train-step tokens/sec -- the trainer's own step
+    (movenet_amd/pytorch_lightning_trainer.py): forward + cross_entropy on the probabilities (Q2)
+    as one fused node, backward through the HIP kernels, ONE flat gradient all-reduce when
+    world > 1, FlatAdamW.  config 2 = BASELINE configs[1] (audio only); config 3 = configs[2] /
+    configs[3] per GPU (video frames -> encoder -> up-sampler -> conditioned layers, their
+    gradients included).  Token = one (sequence, time) position with a target: B * (T - RF)."""
+    import numpy as np
     import torch.distributed as dist
-    """Secondary metric M2 (BASELINE.json): train-step tokens/sec on config 2 --
-    forward (probabilities), cross_entropy on them (Q2), backward through the HIP
-    kernels, one flat gradient all-reduce when world > 1, AdamW.  Token = one
-    (sequence, time) position with a target: B * (T - RF)."""
-    from movenet_amd.ops import wavenet_forward_loss
     from movenet_amd.optim import FlatAdamW, order_like_backward
     from movenet_amd.parallel import FlatGradSync
     from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices
     from movenet_amd.wavenet import WaveNet
-    model = WaveNet(**CFG)
-    model.load_state_dict(make_state_dict(**CFG, seed=0))
-    model.to(dev).train()
-    opt = FlatAdamW(order_like_backward(model), lr=1e-4)  # torch.optim.AdamW's rule, one kernel
-    sync = FlatGradSync(model.parameters(), world)
-    sync.broadcast_parameters(0)
-    Q, rf = CFG["input_channels"], 3072
-    audio = one_hot(synthetic_indices(batch, t_len, Q, 1234 + rank).to(dev), Q)
-    target = audio[:, :, rf:].argmax(1)
+    wl = TRAIN_WORKLOADS[config]
+    batch, t_len, frames = wl["batch"], wl["t_len"], wl["frames"]
+    with clip_frames(frames or 160):
+        model = WaveNet(**CFG)
+        model.load_state_dict(make_state_dict(**CFG, seed=0), strict=not frames)
+        model.to(dev).train()
+        # torch.optim.AdamW's rule, one kernel over one flat buffer
+        opt = FlatAdamW(order_like_backward(model, with_context=bool(frames)), lr=1e-4)
+        sync = FlatGradSync(model.parameters(), world)
+        sync.broadcast_parameters(0)
+        Q, rf = CFG["input_channels"], model.receptive_fields
+        audio = one_hot(synthetic_indices(batch, t_len, Q, 1234 + rank).to(dev), Q)
+        target = audio[:, :, rf:].argmax(1)
+        video = None
+        if frames:  # U[0,1) frames, seed 4321 + rank (SURVEY 8d)
+            video = torch.from_numpy(np.random.default_rng(4321 + rank).random(
+                (batch, frames, 64, 64, 1), dtype=np.float32)).to(dev)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss, _, _ = wavenet_forward_loss(model, audio, None, target)  # the trainer's fused step
-        loss.backward()
-        sync.sync_gradients()
-        opt.step()
-        return loss
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = model(audio, video, return_loss=True, target=target)  # the trainer's fused step
+            loss.backward()
+            sync.sync_gradients()
+            opt.step()
+            return loss
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    marks[0].record()
-    for i in range(steps):
-        loss = step()
-        marks[i + 1].record()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    log(f"rank {rank}: train steps (ms) "
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record()
+        for i in range(steps):
+            loss = step()
+            marks[i + 1].record()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    log(f"rank {rank}: config-{config} train steps (ms) "
         f"{[round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(steps)]}")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -222,18 +286,44 @@ def train_leg(dev, world, rank, steps=6, warmup=5, batch=16, t_len=16000):
     if world > 1:
         digests = [None] * world
         dist.all_gather_object(digests, digest)
-    tokens = world * batch * (t_len - rf) * steps
-    # 5,441,508 FLOP per token (fwd + bwd = 3 x forward MACs x 2)
-    flop_per_token = 5441508
-    tf = tokens * flop_per_token / dt / 1e12
-    return {"metric": "train-step tokens/sec", "value": tokens / dt, "unit": "tokens/s",
+    tokens_per_step = world * batch * (t_len - rf)
+    flop_step = train_flop_per_step(CFG, batch, t_len, frames)  # per GPU
+    tf = flop_step * steps / dt / 1e12
+    return {"metric": "train-step tokens/sec", "value": tokens_per_step * steps / dt, "unit": "tokens/s",
+            "workload": wl["name"], "conditioned": bool(frames),
             "ms_per_step": dt / steps * 1e3, "global_batch": world * batch, "seq_len": t_len,
-            "tokens_per_step": world * batch * (t_len - rf), "optimizer": "AdamW", "dtype": "f32",
-            "loss": float(loss.detach()),
+            "tokens_per_step": tokens_per_step, "optimizer": "AdamW (FlatAdamW, one launch)", "dtype": "f32",
+            "loss": float(loss.detach()), "optimizer_launches_per_step": opt.last_launches,
             "param_sha256_per_rank": digests, "allreduce_path": sync.last_path,
             "allreduce_floats": sync.last_floats,
-            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf / world / FP32_PEAK_TFLOPS}}
+            "flop_per_step_per_gpu": flop_step, "flop_per_token": flop_step / (batch * (t_len - rf)),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS}}
+
+
+def trainer_fit_line(dev, steps=8):
+    """The SAME config-2 step driven by the trainer entry point's own loop (Trainer.fit: loader,
+    training_step, gradient-norm tracking as the reference's track_grad_norm=2, optimizer,
+    OneCycleLR, logging): two epochs of `steps` batches, the second one timed (the first holds
+    code-object loading and allocator growth)."""
+    import contextlib
+    from movenet_amd.config import ModelConfig, TrainingConfig
+    from movenet_amd.pytorch_lightning_trainer import Dance2Music, Trainer
+    wl = TRAIN_WORKLOADS[2]
+    cfg = TrainingConfig(model_config=ModelConfig(**CFG), batch_size=wl["batch"], val_batch_size=wl["batch"],
+                         use_video=False, n_epochs=2, optimizer="AdamW", scheduler="OneCycleLR")
+    spec = f"synthetic://clips={wl['batch'] * steps},frames={wl['t_len']},seed=1234"
+    with contextlib.redirect_stdout(sys.stderr):  # the loop prints its records; stdout is the JSON line's
+        torch.manual_seed(0)
+        module = Dance2Music(spec, cfg)
+        trainer = Trainer(max_epochs=2, default_root_dir=None, gradient_clip_val=0.0, log_every_n_steps=1,
+                          track_grad_norm=2, limit_train_batches=steps, device=str(dev),
+                          enable_checkpointing=False, limit_val_batches=1)
+        trainer.fit(module)
+    ms = trainer.epoch_seconds[-1] / steps * 1e3
+    return {"what": "Trainer.fit, config 2, second of two epochs", "steps": steps, "ms_per_step": ms,
+            "tokens_per_s": wl["batch"] * (wl["t_len"] - 3072) / (ms / 1e3),
+            "track_grad_norm": 2, "last_record": trainer.history[-1]}
 
 
 def spawn_ranks(n: int) -> int:
@@ -257,10 +347,113 @@ def spawn_ranks(n: int) -> int:
     return max(abs(rc) for rc in rcs)
 
 
+CFG5 = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
+FP16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 matrix peak (no sparsity)
+
+
+def timed_advance(gen, dev, steps, warm):
+    """(seconds, HIP-event ms) of one ``advance(steps)`` launch after ``warm`` untimed steps."""
+    if warm:
+        gen.advance(warm)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    gen.advance(steps)
+    e1.record()
+    gen.check_errors()
+    return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+
+def config3_generate_line(dev, rank, n_new=16000):
+    """BASELINE configs[2]: the config-2 model + video conditioning, 8 clips of 32 frames
+    (T = 32000), greedy generate of 16000 samples per clip through the generator (context
+    convs folded into the past-tap precompute of the pipelined kernel)."""
+    import numpy as np
+    from movenet_amd.generation import RingGenerator
+    from movenet_amd.utils.weights import make_state_dict, synthetic_indices
+    from movenet_amd.wavenet import WaveNet
+    B, F = 8, 32
+    with clip_frames(F):
+        model = WaveNet(**CFG)
+        model.load_state_dict(make_state_dict(**CFG, seed=0), strict=False)
+        model.to(dev).eval()
+        video = torch.from_numpy(np.random.default_rng(4321 + rank).random((B, F, 64, 64, 1), dtype=np.float32)).to(dev)
+        with torch.no_grad():
+            context = model.upsample_video(video)
+    rf = model.receptive_fields
+    g = RingGenerator(**CFG, state_dict=model._decoder_state(), batch=B, n_total=rf + n_new + n_new // 10 + 1,
+                      device=dev, temperature=0.0, seed=0, context=context)
+    g.prime(synthetic_indices(B, rf, CFG["input_channels"], 1234 + rank).to(dev))
+    dt, ms = timed_advance(g, dev, n_new, n_new // 10)
+    C, K, Q, L = 64, 64, 256, 30
+    flop = 2 * (L * (7 * C * C + C * K) + K * Q + Q * Q)  # SURVEY 8d: 2,129,920 with conditioning
+    tf = flop * B * n_new / (ms / 1e3) / 1e12
+    return {"workload": "BASELINE configs[2]: config 2 + video conditioning, 32-frame clips, batch 8, greedy",
+            "samples_per_s": B * n_new / dt, "us_per_sample_step": dt / n_new * 1e6, "launch_ms": ms,
+            "kernel_variant": g.variant, "flop_per_sample": flop,
+            "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP32_PEAK_TFLOPS}}
+
+
+def config5_lines(dev, rank, n_new=22050):
+    """BASELINE configs[4]: 60-layer WaveNet, C = K = 128, 22.05 kHz, autoregressive generate of 1 s
+    of audio (22050 samples), batch 1 -- in fp32 (the reference's precision) and with fp16
+    operands / fp32 accumulation (the config as written)."""
+    from movenet_amd import _native as N
+    from movenet_amd.generation import RingGenerator
+    from movenet_amd.utils.weights import make_state_dict, synthetic_indices
+    sd5 = {k: v.to(dev) for k, v in make_state_dict(**CFG5, seed=0).items() if not k.startswith("video_")}
+    rf = 6144
+    flop = flop_per_sample(CFG5)  # 11,993,088
+    out = {"workload": "BASELINE configs[4]: 60-layer (10x6) WaveNet, Q=256, C=K=128, 22.05 kHz, batch 1, "
+                       "greedy generate of 22050 samples (1 s of audio)", "flop_per_sample": flop}
+    for key, variant, peak, bound in (("fp32", N.GEN_PIPE, FP32_PEAK_TFLOPS, "valu_fp32"),
+                                      ("fp16_operands_fp32_accumulate", N.GEN_PIPE_F16, FP16_DENSE_PEAK_TFLOPS,
+                                       "valu_fp16_dot2 (priced against the dense fp16 MATRIX peak)")):
+        g = RingGenerator(**CFG5, state_dict=sd5, batch=1, n_total=rf + n_new + n_new // 10 + 1, device=dev,
+                          variant=variant, temperature=0.0, seed=0)
+        g.prime(synthetic_indices(1, rf, 256, 1234 + rank).to(dev))
+        dt, ms = timed_advance(g, dev, n_new, n_new // 10)
+        tf = flop * n_new / (ms / 1e3) / 1e12
+        out[key] = {"us_per_sample_step": dt / n_new * 1e6, "seconds_per_second_of_audio": dt,
+                    "real_time": dt <= 1.0, "samples_per_s": n_new / dt, "launch_ms": ms,
+                    "kernel_variant": g.variant,
+                    "roofline": {"bound": bound, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}}
+        del g
+    return out
+
+
+def batch_sweep_lines(dev, sd, rf, rank, n_new=4000):
+    """Samples/s of the config-2 generator beyond the headline's 16 sequences per GPU (what
+    MVN_GEN_AUTO picks for each batch; greedy)."""
+    from movenet_amd import _native as N
+    from movenet_amd.generation import GroupedGenerator, RingGenerator, auto_plan
+    from movenet_amd.utils.weights import synthetic_indices
+    out = {}
+    dims = N.make_dims(*(CFG[k] for k in ("layer_size", "stack_size", "input_channels", "residual_channels",
+                                          "skip_channels")))
+    for B in (16, 64, 128):
+        kind, group, variant = auto_plan(dims, B, False)
+        kw = dict(state_dict=sd, batch=B, n_total=rf + n_new + n_new // 10 + 1, device=dev, variant=variant,
+                  temperature=0.0, seed=0)
+        g = GroupedGenerator(**CFG, group=group, **kw) if kind == "grouped" else RingGenerator(**CFG, **kw)
+        g.prime(synthetic_indices(B, rf, CFG["input_channels"], 1234 + rank).to(dev))
+        dt, ms = timed_advance(g, dev, n_new, n_new // 10)
+        tf = flop_per_sample(CFG) * B * n_new / dt / 1e12
+        out[str(B)] = {"samples_per_s": B * n_new / dt, "us_per_step_of_all_sequences": dt / n_new * 1e6,
+                       "plan": [kind, group, variant],
+                       "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS}}
+        del g
+    return out
+
+
 def extra_lines(dev, sd, rf, n_new, rank):
-    """Figures quoted beside the headline (same workload, outside the timed steps): sampling at
-    the reference's default temperature 1.0, and one END-TO-END WaveNet.generate call
-    (one-hot prompt in HBM -> indices -> priming -> 16000 steps -> one-hot out)."""
+    """Figures quoted beside the headline (outside the timed steps): sampling at the reference's
+    default temperature 1.0, one END-TO-END WaveNet.generate call (one-hot prompt in HBM ->
+    indices -> priming -> 16000 steps -> one-hot out), the generator beyond 16 sequences, and
+    BASELINE configs[2] (conditioned) / configs[4] (60 layers, C = 128, fp32 and fp16) generate."""
     from movenet_amd.generation import RingGenerator
     from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices
     from movenet_amd.wavenet import WaveNet
@@ -293,6 +486,15 @@ def extra_lines(dev, sd, rf, n_new, rank):
     out["end_to_end_generate_samples_per_s"] = BATCH * n_new / dt
     out["end_to_end_generate_ms"] = dt * 1e3
     out["end_to_end_fallback_variant"] = model.last_generate_fallback
+    del model, audio, y
+    for key, fn in (("batch_sweep", lambda: batch_sweep_lines(dev, sd, rf, rank)),
+                    ("config3_generate", lambda: config3_generate_line(dev, rank)),
+                    ("config5", lambda: config5_lines(dev, rank))):
+        try:
+            out[key] = fn()
+        except Exception as e:  # one missing figure must not take the others with it
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        log(f"rank {rank}: extras.{key} {out[key]}")
     return out
 
 
@@ -307,6 +509,15 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the T=1.0 and end-to-end lines")
     args = ap.parse_args()
+
+    if os.environ.get("MOVENET_BENCH_DUMP_MAPS") == "1":
+        # diagnostics: the executable mappings of the process, to resolve a native stack trace
+        import atexit
+
+        def _dump_maps():
+            with open("/proc/self/maps") as f:
+                sys.stderr.write("".join(l for l in f if " r-xp " in l))
+        atexit.register(_dump_maps)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -396,15 +607,35 @@ def main():
     # have come and gone, the same training step takes 21-24 ms instead of 17.5 on the same box --
     # every HBM-bound kernel slower, the slab reduces 3x -- with or without empty_cache(); device
     # memory handed back fragmented is our reading, not verified)
-    train = None
+    train, train3, fit = None, None, None
     if not args.no_train_leg:
-        try:
-            del gen
+        del gen
+        torch.cuda.empty_cache()
+        # both M2 workloads at every N: config 2 (audio only, BASELINE configs[1]) and config 3
+        # (video-conditioned, 8 clips of 32 frames per GPU = BASELINE configs[2]; at N = 8 that IS
+        # configs[3], batch 64) -- so each has its own 1/2/4/8 curve on ONE workload
+        for cfgn in (2, 3):
+            try:
+                line = train_leg(dev, world, rank, config=cfgn)
+                log(f"rank {rank}: config-{cfgn} train leg {line['value']:.0f} tokens/s")
+            except Exception as e:  # the headline metric must survive a failure here
+                if world > 1:
+                    raise  # ... but ranks must not diverge around collectives
+                line = {"error": f"{type(e).__name__}: {e}"}
+            if cfgn == 2:
+                train = line
+            else:
+                train3 = line
             torch.cuda.empty_cache()
-            train = train_leg(dev, world, rank)
-            log(f"rank {rank}: train leg {train['value']:.0f} tokens/s")
-        except Exception as e:  # the headline metric must survive a failure here
-            train = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1:
+            try:
+                fit = trainer_fit_line(dev)
+                if train and "ms_per_step" in train:
+                    fit["vs_train_step"] = fit["ms_per_step"] / train["ms_per_step"]
+                log(f"rank 0: Trainer.fit {fit['ms_per_step']:.2f} ms per step")
+            except Exception as e:
+                fit = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
 
     extras = None
     if rank == 0 and not args.no_extras:
@@ -451,15 +682,16 @@ def main():
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_PEAK_TFLOPS,
-                # HBM-side bytes per launch: FETCH_SIZE (as reported: 4/8-byte accesses, the
-                # guide's x2 correction is calibrated for 16-B streams only) + WRITE_SIZE of
-                # separate rocprofv3 --pmc passes, scaled to this launch
-                "traffic": (PMC_TRAFFIC[variant_used]["bytes_per_step_seq"] * BATCH * n_new
-                            if variant_used in PMC_TRAFFIC else None),
-                "traffic_source": (f"constant from {PMC_TRAFFIC[variant_used]['source']} (earlier --pmc passes "
-                                   "of this command); not measured by this run"
-                                   if variant_used in PMC_TRAFFIC else None),
-                "traffic_unit": "bytes per launch (HBM side; the 12.6 MB of dilation queues stay in L2/MALL)",
+                # HBM-side bytes: not measurable from inside the run (hardware counters need a
+                # rocprofv3 --pmc pass) => null here; the last profiled figure is quoted beside it,
+                # labelled as such (FETCH_SIZE as reported + WRITE_SIZE of separate passes)
+                "traffic": None,
+                "traffic_profiled": ({"bytes_per_launch": PMC_TRAFFIC[variant_used]["bytes_per_step_seq"] * BATCH * n_new,
+                                      "source": PMC_TRAFFIC[variant_used]["source"],
+                                      "note": "from earlier --pmc passes of this command, NOT this run; the 12.6 MB "
+                                              "of dilation queues stay in L2/MALL"}
+                                     if variant_used in PMC_TRAFFIC else None),
+                "algorithmic_bytes_per_launch": 2 * 30 * 64 * 4 * BATCH * n_new,  # 15,360 B per sample
                 "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>",
                            5: "gen_fold_kernel"}[variant_used],
                 "flop_per_launch": flops_per_launch,
@@ -468,6 +700,8 @@ def main():
             },
         }
         out["train_step"] = train
+        out["train_step_config3"] = train3
+        out["trainer_fit"] = fit
         out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(sd_cpu)

@@ -359,6 +359,217 @@ static void flush_pending_rs(PendingRsReduce<WgOp> &p, hipStream_t s) {
 }
 
 // ----------------------------------------------------------------------------------------
+// Conditioned layers (BASELINE configs[2]/[3]; the build definition of movenet/modules.py:58-63,
+// :75-77): f | g += Wc ctx + bc.  Its backward, from the SAME dfg tile the first half wrote:
+//   dctx[t]  += Wcf^T df[t] + Wcg^T dg[t]                       (accumulated over the layers)
+//   dWcf|dWcg += dfg ctx^T,   dbcf|dbcg += sum_t dfg
+// This is the first half's shape with other operands -- A = dfg (128 rows), "z" = ctx (64 rows),
+// W = [Wcf; Wcg] (128 x 64) in registers for the transposed product, weight gradient as wgrad2 --
+// so it is the same structure: one staging pass per 64-step tile, the next tile's loads in
+// registers under the MFMAs, slabs in wgrad2's format (reduce_rs64_kernel<WgCtxOp>).  The
+// accumulated dctx tile is staged with the operands and updated IN LDS by the lane that owns the
+// element (no staging copy of the product: two barriers per tile, not three).
+// Replaces wgrad2<WgFgOpT<true>, 2> (192 operand rows: 207 us per layer at config 3) +
+// gemm_wx_staged<DctxOp> (68 us) and lets the audio taps run in bwd_dx_wgfg64_kernel (the generic
+// Dx took 138 us): r2 434 us per layer of second-half work.
+// ----------------------------------------------------------------------------------------
+struct FusedBwdCArgs {
+  int t_begin, t_end;       // the layer's outputs cover [t_begin = A_{l+1}, t_end)
+  const float *wcf, *wcg;   // (64 out, 64 in) each
+  Act dfg, ctx, dctx;       // dfg (B, 128, Tp) read; ctx (B, 64, ld) read; dctx (B, 64, Tp) accumulated in place
+};
+
+struct WgCtxOp {  // where the context-conv gradients go (rows: filter | gate)
+  float *dwcf, *dwcg, *dbcf, *dbcg;
+  __device__ __forceinline__ float *dw(int m, int n) const {
+    if (m >= 2 * FB_C || n >= FB_C) return nullptr;
+    return (m < FB_C ? dwcf + (size_t)m * FB_C : dwcg + (size_t)(m - FB_C) * FB_C) + n;
+  }
+  __device__ __forceinline__ float *db(int m) const {
+    if (m >= 2 * FB_C) return nullptr;
+    return m < FB_C ? dbcf + m : dbcg + (m - FB_C);
+  }
+};
+
+__global__ __launch_bounds__(256, 2) void bwd_dctx_wgctx64_kernel(FusedBwdCArgs a, int chunks_per_b, int chunk_t,
+                                                                 float *__restrict__ bias_part,
+                                                                 float *__restrict__ part) {
+  constexpr int C = FB_C, LD = W2_LD, TT = W2_T;
+  __shared__ __attribute__((aligned(16))) float As[2 * C][LD];  // df rows | dg rows
+  __shared__ __attribute__((aligned(16))) float Cx[C][LD];      // the context
+  __shared__ __attribute__((aligned(16))) float Dc[C][LD];      // dctx so far; updated in place
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5, h4 = 4 * lh;
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+
+  // ---- B operand of the dctx product: W[o][32 wc + li] for o = 2 kk + lh, in registers
+  const int wt = wave >> 1, wc = wave & 1;  // block: t in [32 wt, +32), c in [32 wc, +32)
+  float wreg[C];
+#pragma unroll
+  for (int kk = 0; kk < C; ++kk) {
+    const int o = 2 * kk + lh;
+    wreg[kk] = o < C ? a.wcf[(size_t)o * C + 32 * wc + li] : a.wcg[(size_t)(o - C) * C + 32 * wc + li];
+  }
+  // weight-gradient block of this wave: rows [64 wm, +64), cols [32 wn, +32)
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 accw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+
+  // ---- staging: thread -> rows (tid >> 4) + 16 p, columns 4 (tid & 15) .. +3
+  const int srow = tid >> 4, st = 4 * (tid & 15);
+  f4 areg[8], creg[4], dreg[4];
+  float bsum[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
+  const __amdgpu_buffer_rsrc_t dfgb = fb_rsrc(a.dfg.p + (size_t)b * a.dfg.sb);
+  const __amdgpu_buffer_rsrc_t ctxb = fb_rsrc(a.ctx.p + (size_t)b * a.ctx.sb);
+  const __amdgpu_buffer_rsrc_t dcb = fb_rsrc(a.dctx.p + (size_t)b * a.dctx.sb);
+  const int vo_dfg = 4 * (srow * a.dfg.ld + st), vo_ctx = 4 * (srow * a.ctx.ld + st), vo_dc = 4 * (srow * a.dctx.ld + st);
+  auto gload = [&](int t0) {
+    int srow_q = srow;
+    asm volatile("" : "+v"(srow_q));
+    const int t = t0 + st;
+    if (t0 >= a.t_begin && t0 + TT <= te) {  // interior tile: raw buffer loads (see fb_load16)
+      int ld_dfg = 4 * a.dfg.ld, ld_ctx = 4 * a.ctx.ld, ld_dc = 4 * a.dctx.ld;
+      asm volatile("" : "+s"(ld_dfg), "+s"(ld_ctx), "+s"(ld_dc));
+      const int c4 = 4 * t0;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        areg[p] = fb_load16(dfgb, vo_dfg, 16 * p * ld_dfg + c4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        creg[p] = fb_load16(ctxb, vo_ctx, 16 * p * ld_ctx + c4);
+        dreg[p] = fb_load16(dcb, vo_dc, 16 * p * ld_dc + c4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) areg[p] = ld4_edge(a.dfg.at(b, 16 * p + srow_q, 0), t, a.t_begin, te);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        creg[p] = ld4_edge(a.ctx.at(b, 16 * p + srow_q, 0), t, a.t_begin, te);
+        dreg[p] = ld4_edge(a.dctx.at(b, 16 * p + srow_q, 0), t, a.t_begin, te);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      *(f4 *)&As[16 * p + srow][st] = areg[p];
+      bsum[p] += (areg[p].x + areg[p].y) + (areg[p].z + areg[p].w);  // bias gradient = row sums
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *(f4 *)&Cx[16 * p + srow][st] = creg[p];
+      *(f4 *)&Dc[16 * p + srow][st] = dreg[p];
+    }
+  };
+
+  gload(tb);
+  lstore();
+  __syncthreads();
+  for (int t0 = tb; t0 < te; t0 += TT) {
+    const bool more = t0 + TT < te;
+    if (more) gload(t0 + TT);  // the next tile's loads fly under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dctx' (32 t x 32 c) = sum over the 128 rows of the tile
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk)
+      accd = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
+    // ---- weight gradient: (64 x 32) += dfg (64 x 64 t) ctx^T
+#pragma unroll
+    for (int g = 0; g < TT / 8; ++g) {
+      f4 av[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) av[mi] = *(const f4 *)&As[64 * wm + 32 * mi + li][8 * g + h4];
+      const f4 cv = *(const f4 *)&Cx[32 * wn + li][8 * g + h4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          accw[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[mi], j), f4_get(cv, j), accw[mi], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- this lane owns dctx of channel 32 wc + li at t = 32 wt + 8 q + 4 lh + e: add in LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tc = 32 * wt + 8 * q + h4;
+      const f4 o = *(const f4 *)&Dc[32 * wc + li][tc];
+      *(f4 *)&Dc[32 * wc + li][tc] =
+          f4{o.x + accd[4 * q], o.y + accd[4 * q + 1], o.z + accd[4 * q + 2], o.w + accd[4 * q + 3]};
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores
+    __syncthreads();  // the dctx tile is complete AND every wave has read As / Cx
+    {
+      // whole-row float4 stores: rows 16 p + srow, columns t0 + st .. +3, inside [t_begin, te)
+      const int t = t0 + st;
+      float *base = a.dctx.p + (size_t)b * a.dctx.sb + t;
+      if (t >= a.t_begin && t + 3 < te) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          fb_store16(*(const f4 *)&Dc[16 * p + srow][st], dcb, vo_dc, 4 * (16 * p * a.dctx.ld + t0));
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t + e >= a.t_begin && t + e < te) base[(size_t)(16 * p + srow) * a.dctx.ld + e] = Dc[16 * p + srow][st + e];
+      }
+    }
+    // (a thread's lstore() overwrites exactly the Dc elements the same thread has just read for its
+    // global stores; As / Cx were last read before the barrier above)
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  // ---- this workgroup's slab and bias partial sums (wgrad2_kernel's format, m_rows_pad 128, n_cols_pad 64)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 64 * wm + 32 * mi + acc_row(r, lane), n = 32 * wn + li;
+      part[((size_t)blockIdx.x * 128 + m) * 64 + n] = accw[mi][r];
+    }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    float v = bsum[p];  // 16 lanes share a row
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if ((tid & 15) == 0) bias_part[(size_t)blockIdx.x * 128 + 16 * p + srow] = v;
+  }
+}
+
+// Launch geometry of the conditioned pass (the first half's): false when the scratch cannot hold it.
+static bool bwd_dctx_wgctx64_fits(int t_begin, int t_end, int batch, const float *bias_scratch, const float *slab,
+                                  size_t slab_floats, int *chunks, int *chunk_t) {
+  const int nt = t_end - (t_begin & ~TILE_ALIGN);
+  *chunks = 0;
+  *chunk_t = 0;
+  if (t_end <= t_begin || batch <= 0) return true;
+  fb_chunks(nt, batch, 2, chunks, chunk_t);
+  return bias_scratch && slab && (size_t)*chunks * batch * 128 * 64 <= slab_floats;
+}
+static void launch_bwd_dctx_wgctx64(const FusedBwdCArgs &a, const WgCtxOp &op, int batch, float *bias_scratch,
+                                    float *slab, int chunks, int chunk_t, hipStream_t s) {
+  if (chunks <= 0) return;
+  hipLaunchKernelGGL(bwd_dctx_wgctx64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, chunk_t, bias_scratch, slab);
+  hipLaunchKernelGGL(reduce_rs64_kernel<WgCtxOp>, dim3(256 + 4), dim3(32 * RED_SEG), 0, s, op, slab, bias_scratch, chunks * batch);
+}
+
+// ----------------------------------------------------------------------------------------
 // Second half: the gradient w.r.t. the layer input and the filter/gate weight gradients,
 //   dx[u]   = [u >= t_lo] (dxo[u] + W1^T dfg[u]) + [u + d < T] W0^T dfg[u + d]     (B4 of sequence.hip)
 //   dWf|dWg[o][c][tap 1] += dfg[o][t] x[c][t],   [tap 0] += dfg[o][t] x[c][t - d]

@@ -664,11 +664,7 @@ static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *
   u64 *gran = (u64 *)hand;
   GenArgs args = a;
   int nb = batch;
-  static const bool plain = [] {  // MOVENET_PIPE_PLAIN_LAUNCH=1: diagnostics only
-    const char *e = getenv("MOVENET_PIPE_PLAIN_LAUNCH");
-    return e && e[0] == '1';
-  }();
-  if (coop && !plain) {
+  if (coop && pipe_cooperative_launch()) {
     void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
     return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(P::NT), kargs,
                                                 (unsigned)lds_bytes, s),

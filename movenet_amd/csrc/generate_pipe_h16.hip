@@ -572,11 +572,7 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
   u64 *gran = (u64 *)hand;
   GenArgs args = a;
   int nb = batch;
-  static const bool plain = [] {
-    const char *e = getenv("MOVENET_PIPE_PLAIN_LAUNCH");
-    return e && e[0] == '1';
-  }();
-  if (coop && !plain) {
+  if (coop && pipe_cooperative_launch()) {
     void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
     return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)LDS_BYTES, s),
                      "mvn_generate(pipe_f16, cooperative launch)");

@@ -2,6 +2,8 @@
 // generate_pipe_h16.hip: fp16 operands, C = 128): the granule hand-off, cross-lane moves as
 // DPP, the gate, and the step-closing choice (double softmax, arg-max / inverse-CDF sample).
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 #include "gen_common.h"
 
@@ -13,6 +15,24 @@ typedef float4 f4;
 constexpr int PIPE_XCD_CUS = 32;  // CUs per XCD: one workgroup (133 KB of LDS) per CU
 constexpr unsigned PIPE_SPIN_LIMIT = 1u << 23;
 constexpr int PIPE_MAX_GRAN = 256;
+
+// How the pipelined generators are launched.  Default: an ORDINARY launch.  Co-residency of a
+// pipeline's stages is checked on the host with the kernel's own occupancy arithmetic before
+// every launch, a stage that nevertheless starves raises the sticky status word within a bounded
+// spin and the caller reruns on a kernel without hand-offs.
+// MOVENET_PIPE_COOPERATIVE_LAUNCH=1 asks for hipLaunchCooperativeKernel instead (the runtime
+// then also refuses to run the grid beside another kernel of the process).  It is not the
+// default because the cooperative queue the HIP runtime creates for it is torn down at process
+// exit inside libhsa-runtime64 AFTER rocprofiler-sdk has finalised its queue interception:
+// every rocprofv3 run of a process that had made one cooperative launch ended in SIGSEGV at
+// exit (r3: stack resolved in profiles/r03_exit_crash.md; same step time either way).
+inline bool pipe_cooperative_launch() {
+  static const bool on = [] {
+    const char *e = getenv("MOVENET_PIPE_COOPERATIVE_LAUNCH");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
 
 #ifdef MVN_PIPE_STAMPS
 // Diagnostic build only (python -m movenet_amd.csrc.build --stamps): wall-clock

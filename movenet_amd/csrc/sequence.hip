@@ -1241,7 +1241,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   }();
   // (with both fused halves every kernel of the layer loop runs on the caller's stream: no fork,
   // and none of the two event records + waits per layer that go with it -- ~60 gaps of ~8 us per step)
-  const bool all_fused = fused_bwd && C == 64 && Kc == 64 && !has_ctx;
+  const bool all_fused = fused_bwd && C == 64 && Kc == 64;  // (conditioned layers too: bwd_dctx_wgctx64_kernel)
   const bool fork = bias_scratch2 && !no_side && !all_fused;
   hipStream_t s2 = s;
   if (fork) {
@@ -1302,8 +1302,14 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       launch_gemm_staged(dz, C, batch, s);
     }
     signal(1, s);
+    // conditioned layer: dctx and the context-conv gradients as a third fused pass over dfg
+    // (fused_bwd.h), which leaves the audio taps to the fused second half; decided up front from
+    // the scratch sizes -- the generic conditioned path computes taps and context rows TOGETHER
+    int c_chunks = 0, c_chunk_t = 0;
+    const bool fused_c = has_ctx && fused_a && all_fused &&
+                         bwd_dctx_wgctx64_fits(t_lo, T, batch, bias_scratch2, slab, slab_floats, &c_chunks, &c_chunk_t);
     bool fused_b = false;
-    if (fused_bwd && C == 64 && !has_ctx) {
+    if (fused_bwd && C == 64 && (!has_ctx || fused_c)) {
       // dx and the filter/gate weight gradients from ONE pass over dfg (fused_bwd.h)
       FusedBwdBArgs fb;
       fb.t_out0 = A_lo[l]; fb.t_lo = t_lo; fb.t_end = T; fb.d = d;
@@ -1317,6 +1323,15 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       if (rc) return rc;
     }
     flush_pending_rs(pend, s);  // (only if the second half did not take it along)
+    const bool ctx_done = fused_c && fused_b;
+    if (ctx_done) {  // (behind the layer's reduce: the slab scratch is free again)
+      FusedBwdCArgs fc;
+      fc.t_begin = t_lo; fc.t_end = T; fc.wcf = p->ctx_filter_w[l]; fc.wcg = p->ctx_gate_w[l];
+      fc.dfg = dfg; fc.ctx = ctxv; fc.dctx = dctxv;
+      WgCtxOp co;
+      co.dwcf = gr->ctx_filter_w[l]; co.dwcg = gr->ctx_gate_w[l]; co.dbcf = gr->ctx_filter_b[l]; co.dbcg = gr->ctx_gate_b[l];
+      launch_bwd_dctx_wgctx64(fc, co, batch, bias_scratch2, slab, c_chunks, c_chunk_t, s);
+    }
     await(1, s2);
     auto run_wf = [&](auto wf) {
       wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = d; wf.dfg = dfg; wf.xin = xin; wf.ctx = ctxv;
@@ -1333,7 +1348,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     if (fused_b) {
     } else if (has_ctx) run_wf(WgFgOpT<true>()); else run_wf(WgFgOpT<false>());
     signal(3, s2);
-    if (has_ctx) {
+    if (has_ctx && !ctx_done) {
       DctxOp dc;
       dc.K = 2 * C; dc.t_begin = t_lo; dc.t_end = T; dc.C = C;
       dc.wcf = p->ctx_filter_w[l]; dc.wcg = p->ctx_gate_w[l]; dc.dfg = dfg; dc.dctx = dctxv;

@@ -59,7 +59,7 @@ class SyntheticLoader:
     def __init__(self, spec: str, input_channels: int, batch_size: int, train: bool = True,
                  rank: int = 0, world_size: int = 1, shuffle: bool = False,
                  batch_subsample_frac: Optional[float] = None, use_video: bool = False,
-                 **_ignored):
+                 device=None, **_ignored):
         cfg = parse_synthetic(spec)
         self.n_clips, self.frames = cfg["clips"], cfg["frames"]
         self.seed = cfg["seed"] + (0 if train else 10007)
@@ -67,6 +67,10 @@ class SyntheticLoader:
         self.rank, self.world = rank, max(world_size, 1)
         self.shuffle, self.frac = shuffle, batch_subsample_frac
         self.use_video = use_video
+        # device (an MI355X) given: the class indices are shipped (B x T x 4 bytes) and the one-hot
+        # (B,Q,T) tensor of the Batch contract is formed THERE (mvn_index_to_onehot, row F2) --
+        # a 16 x 256 x 16000 fp32 one-hot is 262 MB of PCIe traffic per batch otherwise
+        self.device = torch.device(device) if device is not None else None
         if use_video and (self.frames % 1000 or batch_subsample_frac is not None):
             raise ValueError("video batches need frames % 1000 == 0 and no batch_subsample_frac "
                              "(the reference crops audio and video independently, dataset.py:232-242, "
@@ -98,7 +102,10 @@ class SyntheticLoader:
         for s in range(0, len(order), self.batch_size):
             ids = order[s:s + self.batch_size]
             idx = torch.stack([self._clip(i) for i in ids])
-            audio = one_hot(idx, self.Q)
+            if self.device is not None and self.device.type == "cuda":
+                audio = _one_hot_on_device(idx, self.Q, self.device)
+            else:
+                audio = one_hot(idx, self.Q)
             if self.frac is not None:
                 n = math.ceil(audio.shape[-1] * self.frac)
                 start = crop_rng.randint(0, audio.shape[-1] - n)
@@ -110,9 +117,24 @@ class SyntheticLoader:
                 vr = np.random.default_rng(self.seed * 7919 + 4321 + ids[0])
                 video = torch.from_numpy(
                     vr.random((len(ids), self.frames // 1000, 64, 64, 1), dtype=np.float32))
+                if self.device is not None:
+                    video = video.to(self.device, non_blocking=True)
             yield Batch(audio, video, ["synthetic"] * len(ids),
                         [f"synthetic://{i}" for i in ids],
                         [dict(video_fps=0.0, audio_fps=float(self.frames) / 10.0)] * len(ids))
+
+
+def _one_hot_on_device(idx: torch.Tensor, Q: int, device: torch.device) -> torch.Tensor:
+    """(B,T) int64 host indices -> (B,Q,T) fp32 one-hot on ``device`` through the C ABI."""
+    from . import _native as N
+    B, T = idx.shape
+    with torch.cuda.device(device):
+        d_idx = idx.to(torch.int32).to(device, non_blocking=True)
+        out = torch.empty(B, Q, T, dtype=torch.float32, device=device)
+        N.check(N.lib().mvn_index_to_onehot(d_idx.data_ptr(), d_idx.stride(0), out.data_ptr(), B, Q, T,
+                                            torch.cuda.current_stream(device).cuda_stream),
+                "mvn_index_to_onehot")
+    return out
 
 
 def get_dataloader(filepath, input_channels: int, batch_size: int = 64, train: bool = True,
@@ -122,7 +144,8 @@ def get_dataloader(filepath, input_channels: int, batch_size: int = 64, train: b
     """Signature of movenet/dataset.py:59-98."""
     return SyntheticLoader(str(filepath), input_channels, batch_size, train=train, rank=rank,
                            world_size=world_size, shuffle=kwargs.get("shuffle", False),
-                           batch_subsample_frac=batch_subsample_frac, use_video=use_video)
+                           batch_subsample_frac=batch_subsample_frac, use_video=use_video,
+                           device=kwargs.get("device"))
 
 
 # -- mu-law companding: the formula the project states (RESEARCH.md:156-163).

@@ -40,6 +40,32 @@ def decoder_param_names(n_layers: int, with_context: bool = False) -> List[str]:
     return names
 
 
+class VideoGradSlot:
+    """Hand-over between the two autograd nodes of a conditioned step.  The decoder's backward
+    (which runs first: it produces the context gradient) allocates ONE zero-filled flat buffer
+    for its own gradients AND the eight video-encoder gradients behind them, in the order
+    ``optim.order_like_backward(model, with_context=True)`` lays the parameters out; the
+    up-sampler's backward then writes into those views instead of eight buffers of its own.
+    One storage => one all-reduce message (parallel.contiguous_grad_span) and one AdamW launch."""
+
+    def __init__(self, shapes):
+        self.shapes = [tuple(s) for s in shapes]
+        self.sizes = [int(torch.Size(s).numel()) for s in self.shapes]
+        self.total = sum(self.sizes)
+        self.views = None
+
+    def carve(self, tail: torch.Tensor) -> None:
+        views, off = [], 0
+        for shape, k in zip(self.shapes, self.sizes):
+            views.append(tail[off:off + k].view(shape))
+            off += k
+        self.views = views
+
+    def take(self):
+        views, self.views = self.views, None
+        return views
+
+
 class ForwardBuffers:
     """Device buffers of one forward pass (sizes: include/movenet_hip.h)."""
 
@@ -119,6 +145,7 @@ class _WaveNetFunction(torch.autograd.Function):
         ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf = dims, names, idx, buf
         ctx_.normalize, ctx_.remove_last, ctx_.saved_fwd = normalize, remove_last, save
         ctx_.has_context = context is not None
+        ctx_.video_slot = getattr(dims, "_video_slot", None) if context is not None else None
         ctx_.save_for_backward(out, *params)
         return out
 
@@ -149,7 +176,11 @@ def _run_backward(ctx_, params, out, dout, fill_dlogit):
         # fill kernel instead of ~190; FlatGradSync all-reduces the buffer in place and
         # FlatAdamW steps over it with one kernel)
         sizes = [p.numel() for p in params]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        slot = getattr(ctx_, "video_slot", None)
+        flat = torch.zeros(sum(sizes) + (slot.total if slot is not None else 0), dtype=torch.float32,
+                           device=dev)
+        if slot is not None:  # the video encoder's gradients live behind the decoder's
+            slot.carve(flat[sum(sizes):])
         grads, off = {}, 0
         for n, p_, k in zip(names, params, sizes):
             grads[n] = flat[off:off + k].view(p_.shape)
@@ -227,6 +258,7 @@ class _WaveNetLossFunction(torch.autograd.Function):
         ctx_.dims, ctx_.names, ctx_.idx, ctx_.buf = dims, names, idx, buf
         ctx_.normalize, ctx_.remove_last, ctx_.saved_fwd = True, True, save
         ctx_.has_context = context is not None
+        ctx_.video_slot = getattr(dims, "_video_slot", None) if context is not None else None
         ctx_.save_for_backward(out, tg, *params)
         ctx_.mark_non_differentiable(acc, out)
         return loss, acc, out
@@ -254,7 +286,7 @@ class _UpsampleVideoFunction(torch.autograd.Function):
     """video (B,F,64,64,Cin) -> context (B,C,1000F) through mvn_upsample_video."""
 
     @staticmethod
-    def forward(ctx_, dims, video, *params):
+    def forward(ctx_, dims, slot, video, *params):
         lib = N.lib()
         _require_gpu(video, "video")
         if video.dim() != 5 or video.shape[2] != 64 or video.shape[3] != 64:
@@ -277,7 +309,7 @@ class _UpsampleVideoFunction(torch.autograd.Function):
             N.check(lib.mvn_upsample_video(dims, vp, video.data_ptr(), B, F, cin, enc.data_ptr(),
                                            u1.data_ptr(), u2.data_ptr(), out.data_ptr(),
                                            out.stride(1), _stream_ptr(dev)), "mvn_upsample_video")
-        ctx_.dims, ctx_.shape = dims, (B, F, cin)
+        ctx_.dims, ctx_.shape, ctx_.slot = dims, (B, F, cin), slot
         ctx_.save_for_backward(video, enc, u1, u2, *ps)
         return out
 
@@ -290,7 +322,11 @@ class _UpsampleVideoFunction(torch.autograd.Function):
         dev = video.device
         dout = dout.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
-            grads = [torch.zeros_like(p) for p in ps]
+            # zero-filled views behind the decoder's gradients when its backward has run (the
+            # usual case: it produced dout), else eight buffers of this node's own
+            grads = ctx_.slot.take() if ctx_.slot is not None else None
+            if grads is None or grads[0].device != dev:
+                grads = [torch.zeros_like(p) for p in ps]
             vp = N.VideoParams(ps[0].data_ptr(), ps[1].data_ptr(),
                                (C_void3)(ps[2].data_ptr(), ps[4].data_ptr(), ps[6].data_ptr()),
                                (C_void3)(ps[3].data_ptr(), ps[5].data_ptr(), ps[7].data_ptr()))
@@ -302,22 +338,28 @@ class _UpsampleVideoFunction(torch.autograd.Function):
                 dims, vp, vg, video.data_ptr(), B, F, cin, enc.data_ptr(), u1.data_ptr(),
                 u2.data_ptr(), dout.data_ptr(), dout.stride(1), d_u2.data_ptr(), d_u1.data_ptr(),
                 d_enc.data_ptr(), _stream_ptr(dev)), "mvn_upsample_video_backward")
-        need = ctx_.needs_input_grad[2:]
-        return (None, None, *[g if w else None for g, w in zip(grads, need)])
+        need = ctx_.needs_input_grad[3:]
+        return (None, None, None, *[g if w else None for g, w in zip(grads, need)])
 
 
 def upsample_video(model, video: torch.Tensor) -> torch.Tensor:
     lookup = dict(model.named_parameters())
-    return _UpsampleVideoFunction.apply(model._dims, video, *[lookup[n] for n in VIDEO_PARAMS])
+    vparams = [lookup[n] for n in VIDEO_PARAMS]
+    slot = VideoGradSlot([p.shape for p in vparams]) if all(p.requires_grad for p in vparams) else None
+    out = _UpsampleVideoFunction.apply(model._dims, slot, video, *vparams)
+    if slot is not None and out.requires_grad:
+        out._mvn_video_slot = slot  # read back by wavenet_forward / wavenet_forward_loss
+    return out
 
 
-def _tagged_dims(dims, f16: bool = False):
+def _tagged_dims(dims, f16: bool = False, context=None):
     """A copy of the dims struct carrying what the autograd Functions cannot see from inside
     ``forward``: whether grad mode was on at the call, and the operand precision."""
     d = N.make_dims(dims.layer_size, dims.stack_size, dims.input_channels, dims.residual_channels,
                     dims.skip_channels)
     d._grad_mode = torch.is_grad_enabled()
     d._f16 = f16
+    d._video_slot = getattr(context, "_mvn_video_slot", None) if context is not None else None
     return d
 
 
@@ -338,10 +380,13 @@ def wavenet_forward(model, audio: torch.Tensor, context=None, output_unnormalize
     model.compute_output_size(audio)  # ValueError when T < RF, like the reference
     idx, check = model._indices_async(audio)
     names, params = _decoder_params(model, context is not None)
-    dims = _tagged_dims(model._dims, f16=model.forward_precision == "fp16")
+    dims = _tagged_dims(model._dims, f16=model.forward_precision == "fp16", context=context)
     out = _WaveNetFunction.apply(dims, names, idx, bool(output_unnormalized),
                                  bool(remove_last), context, *params)
     if not model._all_one_hot(check):  # dense causal conv on the tensor itself
+        # (a dense input pays the discarded index pass: one extra forward; its buffers --
+        # saved activations included -- are released BEFORE the rerun allocates its own)
+        del out
         dense = audio.detach().to(torch.float32).contiguous()
         out = _WaveNetFunction.apply(dims, names, dense, bool(output_unnormalized),
                                      bool(remove_last), context, *params)
@@ -360,9 +405,10 @@ def wavenet_forward_loss(model, audio: torch.Tensor, context=None, target=None):
     idx, check = model._indices_async(audio)
     names, params = _decoder_params(model, context is not None)
     tg = idx[:, rf:].to(torch.int64) if target is None else target
-    dims = _tagged_dims(model._dims)
+    dims = _tagged_dims(model._dims, context=context)
     res = _WaveNetLossFunction.apply(dims, names, idx, tg, context, *params)
     if not model._all_one_hot(check):  # (read after the enqueue: no idle GPU) dense causal conv
+        del res  # release the discarded pass (saved activations) before the rerun allocates
         dense = audio.detach().to(torch.float32).contiguous()
         tg = audio[:, :, rf:].argmax(1) if target is None else target
         res = _WaveNetLossFunction.apply(dims, names, dense, tg, context, *params)

@@ -61,6 +61,25 @@ class FlatAdamW(torch.optim.Optimizer):
         self.last_launches = 0
 
     # ------------------------------------------------------------------
+    def load_state_dict(self, state_dict) -> None:
+        """torch's ``Optimizer.load_state_dict`` REPLACES ``self.state`` with new objects; the
+        moments this optimizer steps over are the flat buffers made in the constructor, so the
+        loaded moments and per-parameter step counts are copied INTO them (and ``self.state``
+        is pointed back at them): a resumed run continues where the saved one stopped."""
+        flat = state_dict["state"].get("flat") if "state" in state_dict else None
+        if flat is None:
+            raise ValueError("FlatAdamW.load_state_dict: no 'flat' entry (not a FlatAdamW state_dict)")
+        steps, m, v = list(flat["steps"]), flat["exp_avg"], flat["exp_avg_sq"]
+        if len(steps) != len(self._params) or m.numel() != self._n or v.numel() != self._n:
+            raise ValueError(f"FlatAdamW.load_state_dict: saved state covers {len(steps)} parameters / "
+                             f"{m.numel()} elements, this optimizer {len(self._params)} / {self._n}")
+        super().load_state_dict(state_dict)  # param_groups (lr, betas, ...) as torch does it
+        with torch.no_grad():
+            self.exp_avg.copy_(m.reshape(-1))
+            self.exp_avg_sq.copy_(v.reshape(-1))
+        self._steps[:] = [int(x) for x in steps]
+        self.state["flat"] = {"steps": self._steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+
     def _launch(self, p_ptr, g_ptr, m_ptr, v_ptr, n, step, skips, stream) -> None:
         grp = self.param_groups[0]
         arr = (ctypes.c_size_t * max(2 * len(skips), 1))(*[x for r in skips for x in r])

@@ -39,10 +39,39 @@ def init_distributed(backend: Optional[str] = None, port: str = "8888") -> tuple
     return rank, world, local_rank
 
 
+def contiguous_grad_span(used: List[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+    """One 1-D tensor covering every gradient of ``used`` when they are contiguous,
+    non-overlapping views inside ONE storage -- in ANY order (the decoder's backward lays its
+    gradients out in its own order, ops.decoder_param_names, not in registration order); gaps
+    are allowed: parameters without a gradient lie there and the buffer is zero-filled, so a gap
+    is zero on every rank.  Otherwise None."""
+    if not used:
+        return None
+    g0 = used[0].grad
+    store = g0.untyped_storage()
+    spans = []
+    for p in used:
+        g = p.grad
+        if (g.dtype != g0.dtype or g.device != g0.device or not g.is_contiguous() or
+                g.untyped_storage().data_ptr() != store.data_ptr()):
+            return None
+        spans.append((g.storage_offset(), g.storage_offset() + g.numel()))
+    spans.sort()
+    for (_, end), (beg, _) in zip(spans, spans[1:]):
+        if beg < end:  # two gradients share elements: not a partition of the buffer
+            return None
+    lo, hi = spans[0][0], spans[-1][1]
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(store, lo, (hi - lo,))
+
+
 class FlatGradSync:
     """Broadcast parameters once, then average gradients with one all-reduce."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], world: Optional[int] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], world: Optional[int] = None,
+                 single_rank_collective: bool = False):
+        """``single_rank_collective``: run the all-reduce even in a world of one (a process
+        group must exist) -- lets a one-GPU box execute the RCCL path itself."""
+        self.single_rank_collective = bool(single_rank_collective)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (
             dist.get_world_size() if dist.is_initialized() else 1)
@@ -64,24 +93,7 @@ class FlatGradSync:
 
     @staticmethod
     def _contiguous_span(used: List[torch.nn.Parameter]) -> Optional[torch.Tensor]:
-        """One 1-D tensor covering every gradient when they are contiguous views laid out in
-        increasing order inside ONE storage (gaps allowed: parameters without a gradient lie
-        between them and are zero on every rank), else None."""
-        g0 = used[0].grad
-        store = g0.untyped_storage()
-        lo, hi, prev_end = None, None, None
-        for p in used:
-            g = p.grad
-            if (g.dtype != g0.dtype or not g.is_contiguous() or
-                    g.untyped_storage().data_ptr() != store.data_ptr()):
-                return None
-            beg = g.storage_offset()
-            if prev_end is not None and beg < prev_end:
-                return None
-            prev_end = beg + g.numel()
-            lo = beg if lo is None else lo
-            hi = prev_end
-        return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(store, lo, (hi - lo,))
+        return contiguous_grad_span(used)
 
     def sync_gradients(self) -> int:
         """Average .grad over ranks; returns the number of floats sent.  The set
@@ -89,7 +101,7 @@ class FlatGradSync:
         depends only on the model and on use_video)."""
         used = [p for p in self.params if p.grad is not None]
         n = sum(p.grad.numel() for p in used)
-        if self.world <= 1 or n == 0:
+        if n == 0 or (self.world <= 1 and not (self.single_rank_collective and dist.is_initialized())):
             self.last_path, self.last_floats = "none", 0
             return 0
         span = self._contiguous_span(used)

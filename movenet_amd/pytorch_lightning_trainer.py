@@ -28,9 +28,8 @@ import torch.nn as nn
 
 from .config import TrainingConfig, arg_parser, config_from_args
 from .dataset import get_dataloader
-from .ops import wavenet_forward_loss
 from .optim import FlatAdamW, order_like_backward
-from .parallel import FlatGradSync, init_distributed
+from .parallel import FlatGradSync, contiguous_grad_span, init_distributed
 from .wavenet import WaveNet
 
 
@@ -44,14 +43,19 @@ class Dance2Music(nn.Module):
         self.current_epoch = 0
         self.precision = 32
         self.rank, self.world_size = 0, 1
-        self.logged = {}
+        self.logged_raw = {}  # name -> 0-dim device tensor or float, as logged (no host sync)
 
     @property
     def device(self) -> torch.device:
         return next(self.model.parameters()).device
 
+    @property
+    def logged(self) -> dict:
+        """The logged values as floats.  Reading this waits for the GPU; ``log`` does not."""
+        return {k: float(v) for k, v in self.logged_raw.items()}
+
     def log(self, name: str, value, batch_size: Optional[int] = None) -> None:
-        self.logged[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+        self.logged_raw[name] = value.detach() if torch.is_tensor(value) else float(value)
 
     def forward(self, audio, video, **kwargs):
         return self.model(audio, video, **kwargs)
@@ -74,8 +78,9 @@ class Dance2Music(nn.Module):
         # loss = cross_entropy(output, target) on those probabilities (Q2); accuracy -- the
         # reference's lines 62-66 as ONE autograd node: softmax + loss + accuracy in one pass
         # over the head's logits, their gradient in one pass back (ops.wavenet_forward_loss)
-        context = None if video is None else self.model.upsample_video(video)
-        loss, acc, output = wavenet_forward_loss(self.model, audio, context)
+        # (through both modules' __call__, like the reference's self(audio, video): forward
+        # hooks and overrides keep firing)
+        loss, acc, output = self(audio, video if self.config.use_video else None, return_loss=True)
         self.log(f"{prefix}_loss", loss, batch_size=self.config.batch_size)
         self.log(f"{prefix}_acc", acc, batch_size=self.config.batch_size)
         return loss, output, audio, video
@@ -96,7 +101,10 @@ class Dance2Music(nn.Module):
             batch_size=c.batch_size if train else c.val_batch_size, train=train,
             rank=self.rank, world_size=self.world_size, shuffle=train, pin_memory=c.pin_memory,
             num_workers=c.num_workers if train else c.val_num_workers, use_video=c.use_video,
-            batch_subsample_frac=c.batch_subsample_frac if train else c.val_batch_subsample_frac)
+            batch_subsample_frac=c.batch_subsample_frac if train else c.val_batch_subsample_frac,
+            # row F2: class indices cross PCIe (4 bytes per sample), the (B,Q,T) one-hot the Batch
+            # contract asks for is formed on the device
+            device=self.device if self.device.type == "cuda" else None)
 
     def train_dataloader(self):
         print("using full audio samples." if self.config.batch_subsample_frac is None
@@ -156,7 +164,7 @@ class Trainer:
                  accumulate_grad_batches: int = 1, logger=None, log_every_n_steps: int = 1,
                  num_sanity_val_steps: int = 0, callbacks=None, track_grad_norm: int = 2,
                  limit_train_batches: Optional[int] = None, device: Optional[str] = None,
-                 enable_checkpointing: bool = True):
+                 enable_checkpointing: bool = True, limit_val_batches: Optional[int] = None):
         self.max_epochs = max_epochs
         self.root = Path(default_root_dir) if default_root_dir is not None else None
         self.clip = gradient_clip_val or 0.0
@@ -164,6 +172,9 @@ class Trainer:
         self.log_every = max(1, log_every_n_steps)
         self.track_grad_norm = track_grad_norm
         self.limit = limit_train_batches
+        # (Lightning's limit_val_batches; default: the training limit, as before)
+        self.limit_val = limit_val_batches if limit_val_batches is not None else limit_train_batches
+        self.epoch_seconds = []  # wall time of each epoch's training loop
         self.device = device
         self.checkpointing = enable_checkpointing
         self.callbacks = list(callbacks or [])
@@ -191,6 +202,21 @@ class Trainer:
         if self.root is not None and rank == 0:
             self.root.mkdir(parents=True, exist_ok=True)
             log_f = open(self.root / "metrics.jsonl", "a")
+        pending = []  # records whose values are still device tensors
+
+        def flush_records():
+            """Resolve the queued records (float() waits for the step that produced them -- which
+            is why a record is resolved only after the NEXT step has been enqueued), append them
+            to history, print / write them."""
+            while pending:
+                rec = {k: (float(v) if torch.is_tensor(v) else v) for k, v in pending.pop(0).items()}
+                self.history.append(rec)
+                if rank == 0 and (rec["step"] + 1) % self.log_every == 0:
+                    print(json.dumps(rec), flush=True)
+                    if log_f:
+                        log_f.write(json.dumps(rec) + "\n")
+                        log_f.flush()
+
         for epoch in range(self.max_epochs):
             model.current_epoch = self.current_epoch = epoch
             model.train()
@@ -208,50 +234,62 @@ class Trainer:
                     cb.on_train_batch_end(self, model, out, batch, batch_idx)
                 if (batch_idx + 1) % self.accum == 0 or batch_idx + 1 == n_batches:
                     sync.sync_gradients()
-                    rec = {"epoch": epoch, "step": self.global_step, **model.logged}
-                    if self.track_grad_norm:
-                        gs = [p.grad.detach().norm(self.track_grad_norm)
-                              for p in model.model.parameters() if p.grad is not None]
-                        rec["grad_norm_total"] = float(torch.stack(gs).norm(self.track_grad_norm))
-                    if self.clip > 0:
-                        torch.nn.utils.clip_grad_norm_(model.model.parameters(), self.clip)
+                    rec = {"epoch": epoch, "step": self.global_step, **model.logged_raw}
+                    used = [p for p in model.model.parameters() if p.grad is not None]
+                    # every gradient is a view of ONE flat buffer (ops._run_backward): the total
+                    # norm is one reduction over that span (parameters without a gradient are
+                    # zero-filled gaps), not one launch per parameter; and nothing here reads a
+                    # value back -- the record is resolved a step later (flush_records)
+                    span = contiguous_grad_span(used) if (self.track_grad_norm or self.clip > 0) and used else None
+                    if self.track_grad_norm and used:
+                        if span is not None:
+                            rec["grad_norm_total"] = span.norm(self.track_grad_norm)
+                        else:
+                            rec["grad_norm_total"] = torch.stack(
+                                [p.grad.detach().norm(self.track_grad_norm) for p in used]).norm(self.track_grad_norm)
+                    if self.clip > 0 and used:
+                        if span is not None:  # torch.nn.utils.clip_grad_norm_'s rule on the span
+                            total = (rec["grad_norm_total"] if self.track_grad_norm == 2 else span.norm(2))
+                            span.mul_((self.clip / (total + 1e-6)).clamp(max=1.0))
+                        else:
+                            torch.nn.utils.clip_grad_norm_(model.model.parameters(), self.clip)
                     optimizer.step()
                     optimizer.zero_grad(set_to_none=True)
                     rec["lr"] = optimizer.param_groups[0]["lr"]
                     if scheduler is not None:
                         scheduler.step()
                     self.global_step += 1
-                    self.history.append(rec)
-                    if rank == 0 and self.global_step % self.log_every == 0:
-                        print(json.dumps(rec), flush=True)
-                        if log_f:
-                            log_f.write(json.dumps(rec) + "\n")
-                            log_f.flush()
+                    flush_records()          # the PREVIOUS step's values: ready by now
+                    pending.append(rec)
+            flush_records()
             torch.cuda.synchronize(dev)
             epoch_s = time.perf_counter() - t0
+            self.epoch_seconds.append(epoch_s)
             model.eval()
             # epoch means of val_loss / val_acc, weighted by batch size and summed over the
             # ranks' shards: what Lightning's self.log(..., on_epoch=True) reports for
             # validation_step (pytorch_lightning_trainer.py:91-92), not the last batch's values
-            val_sum = torch.zeros(3, dtype=torch.float64)  # loss * n, acc * n, n
+            val_dev = torch.zeros(3, dtype=torch.float64, device=dev)  # loss * n, acc * n, n
             with torch.no_grad():
                 for batch_idx, batch in enumerate(model.val_dataloader()):
-                    if self.limit is not None and batch_idx >= self.limit:
+                    if self.limit_val is not None and batch_idx >= self.limit_val:
                         break
                     out = model.validation_step(batch, batch_idx)
                     n = float(out["output"].shape[0])
-                    val_sum += torch.tensor([model.logged["val_loss"] * n, model.logged["val_acc"] * n, n],
-                                            dtype=torch.float64)
+                    val_dev += torch.stack([torch.as_tensor(model.logged_raw["val_loss"], device=dev).double() * n,
+                                            torch.as_tensor(model.logged_raw["val_acc"], device=dev).double() * n,
+                                            torch.tensor(n, dtype=torch.float64, device=dev)])
                     for cb in self.callbacks:
                         cb.on_validation_batch_end(self, model, out, batch, batch_idx, 0)
             if world > 1:
                 import torch.distributed as dist
-                t = val_sum.to(dev) if dist.get_backend() == "nccl" else val_sum
+                t = val_dev if dist.get_backend() == "nccl" else val_dev.cpu()
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                val_sum = t.cpu()
+                val_dev = t
+            val_sum = val_dev.cpu()
             if val_sum[2] > 0:
-                model.logged["val_loss"] = float(val_sum[0] / val_sum[2])
-                model.logged["val_acc"] = float(val_sum[1] / val_sum[2])
+                model.logged_raw["val_loss"] = float(val_sum[0] / val_sum[2])
+                model.logged_raw["val_acc"] = float(val_sum[1] / val_sum[2])
             self.val_epoch_means = {k: v for k, v in model.logged.items() if k.startswith("val")}
             if rank == 0:
                 print(json.dumps({"epoch": epoch, "epoch_seconds": epoch_s,

@@ -17,6 +17,7 @@ their own ``forward`` is never used.
 from __future__ import annotations
 
 import math
+import sys
 from typing import List, Optional
 
 import numpy as np
@@ -39,6 +40,19 @@ def upsample_kernel_size_solver(in_size, out_size, stride=1, padding=0, output_p
     (the ConvTranspose1d length formula); same contract as movenet/wavenet.py:34-47."""
     span = out_size - 1 - output_padding - (in_size - 1) * stride + 2 * padding
     return (int(span / dilation + 1),)
+
+
+# side streams for reading the one-hot check, one per device.  Kept OUTSIDE the module: a
+# torch.Stream in a module's __dict__ makes copy.deepcopy(model) / torch.save(model) fail.
+_CHECK_STREAMS: dict = {}
+
+
+def _check_stream(dev: torch.device):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    side = _CHECK_STREAMS.get(key)
+    if side is None:
+        side = _CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return side
 
 
 class _Named(nn.Module):
@@ -167,10 +181,7 @@ class WaveNet(nn.Module):
         kernels that produced it -- not for whatever the caller has enqueued since."""
         low, ready = check
         dev = low.device
-        side = self.__dict__.get("_check_stream")
-        if side is None or side.device != dev:
-            side = torch.cuda.Stream(device=dev)
-            self.__dict__["_check_stream"] = side
+        side = _check_stream(dev)
         with torch.cuda.stream(side):
             side.wait_event(ready)
             low.record_stream(side)
@@ -210,13 +221,22 @@ class WaveNet(nn.Module):
         return out
 
     def forward(self, audio, video=None, global_features=None, output_unnormalized: bool = True,
-                remove_last: bool = True):
+                remove_last: bool = True, return_loss: bool = False, target=None):
         """BUILD DEFINITION for video != None: the reference raises a shape error at
         modules.py:75-77; here the upsampled video is added to the filter
         and gate pre-activations at the same absolute time (right-aligned, like the
-        residual input at modules.py:84)."""
-        from .ops import wavenet_forward  # HIP full-sequence kernels
+        residual input at modules.py:84).
+
+        ``return_loss=True`` (an extension; the default is the reference's signature and
+        result): returns ``(loss, accuracy, probabilities)`` of the trainer's step -- the
+        reference's ``output = self(audio, video)``, ``target = audio[:, :, RF:].argmax(1)``,
+        ``F.cross_entropy(output, target)`` and accuracy (pytorch_lightning_trainer.py:62-66)
+        -- as ONE autograd node (ops.wavenet_forward_loss); going through ``forward`` keeps
+        module hooks firing on the fused path."""
+        from .ops import wavenet_forward, wavenet_forward_loss  # HIP full-sequence kernels
         context = None if video is None else self.upsample_video(video)
+        if return_loss:
+            return wavenet_forward_loss(self, audio, context, target)
         return wavenet_forward(self, audio, context, output_unnormalized=output_unnormalized,
                                remove_last=remove_last)
 
@@ -279,5 +299,10 @@ class WaveNet(nn.Module):
                 fallback = N.GEN_STREAM if (context is None and lib.mvn_gen_variant(
                     self._dims, N.GEN_STREAM, idx.shape[0]) == N.GEN_STREAM) else N.GEN_GENERIC
             self.last_generate_fallback = fallback
+            name = {N.GEN_STREAM: "STREAM", N.GEN_GENERIC: "GENERIC"}[fallback]
+            print(f"[movenet_amd] generate: pipelined kernel (variant {variant}) timed out waiting for a "
+                  f"co-resident stage; rerunning this call on {name}"
+                  + (" -- fp32 arithmetic instead of the fp16 operands asked for" if variant == N.GEN_PIPE_F16
+                     else ""), file=sys.stderr, flush=True)
             gen = run(fallback, 0)
         return self._one_hot_of(gen.samples, audio.dtype)

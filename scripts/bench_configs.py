@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import movenet_amd.wavenet as W  # noqa: E402
 from movenet_amd import _native as N  # noqa: E402
-from movenet_amd.ops import cross_entropy_on_probs  # noqa: E402
+from movenet_amd.optim import FlatAdamW, order_like_backward  # noqa: E402
 from movenet_amd.utils.weights import make_state_dict, one_hot, synthetic_indices  # noqa: E402
 
 DEV = "cuda:0"
@@ -48,12 +48,13 @@ def train_rate(m, B, T, video=None):
     Q, rf = m.input_channels, m.receptive_fields
     audio = one_hot(synthetic_indices(B, T, Q, 1234).to(DEV), Q)
     target = audio[:, :, rf:].argmax(1)
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    # the trainer's own step: fused forward + loss node, FlatAdamW (one launch)
+    opt = FlatAdamW(order_like_backward(m, with_context=video is not None), lr=1e-4)
     m.train()
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _ = cross_entropy_on_probs(m(audio, video), target)
+        loss, _, _ = m(audio, video, return_loss=True, target=target)
         loss.backward()
         opt.step()
     dt = sync_time(step, reps=3, warm=2)

@@ -1,0 +1,26 @@
+"""Where does a Trainer.fit step spend its host time?  cProfile of bench.trainer_fit_line (config 2,
+two epochs of 8 steps) + per-step wall times.  Usage: python scripts/trainer_fit_profile.py"""
+import cProfile
+import io
+import os
+import pstats
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+pr = cProfile.Profile()
+pr.enable()
+line = bench.trainer_fit_line(dev)
+pr.disable()
+print(line, file=sys.stderr)
+out = io.StringIO()
+pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(45)
+print(out.getvalue())
+out = io.StringIO()
+pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(25)
+print(out.getvalue())

@@ -124,3 +124,51 @@ def test_conditioned_generate_vs_oracle(monkeypatch, cfg, frames, n_new):
     m = _model(cfg, sd)
     out = m.generate(prompt.to(DEV), video.to(DEV), n_samples=N_, temperature=0.0)
     assert np.array_equal(out.argmax(1).cpu().numpy(), ridx)
+
+
+def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypatch):
+    """Conditioned layers at C = K = 64 take THREE fused passes per layer (csrc/fused_bwd.h): dz +
+    residual/skip weight gradients, dx + the audio taps' weight gradients, and -- round 3 --
+    dctx + the context-conv weight / bias gradients from the same dfg tile
+    (bwd_dctx_wgctx64_kernel).  8 clips of 6 frames (T = 6000: ragged against the 64-step tiles,
+    and long enough that the scratch holds the fused form's slabs) against the generic kernels
+    (MOVENET_HIP_NO_FUSED_BACKWARD=1, same process) and torch autograd on the oracle; the video
+    encoder's gradients are in the comparison, so the accumulated dctx is too."""
+    import movenet_amd.wavenet as W
+    frames, B = 6, 8
+    T = 1000 * frames
+    monkeypatch.setattr(W, "MAX_AUDIO_FRAMES", T)
+    monkeypatch.setattr(W, "MAX_VIDEO_FRAMES", frames)
+    cfg = dict(layer_size=3, stack_size=2, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=23, gain=1.5)
+    dims = O.Dims(**cfg)
+    x = one_hot(synthetic_indices(B, T, 256, 1234), 256)
+    video = torch.from_numpy(np.random.default_rng(4321).random((B, frames, 64, 64, 1), dtype=np.float32))
+    target = x[:, :, dims.receptive_fields:].argmax(1)
+
+    def grads(no_fused):
+        if no_fused:
+            monkeypatch.setenv("MOVENET_HIP_NO_FUSED_BACKWARD", "1")
+        else:
+            monkeypatch.delenv("MOVENET_HIP_NO_FUSED_BACKWARD", raising=False)
+        m = _model(cfg, sd).train()
+        loss, _, _ = m(x.to(DEV), video.to(DEV), return_loss=True)
+        loss.backward()
+        return loss.item(), {k: (None if p.grad is None else p.grad.cpu()) for k, p in m.named_parameters()}
+
+    (loss_f, fused), (loss_p, plain) = grads(False), grads(True)
+    assert loss_f == loss_p
+    for k in fused:
+        assert (fused[k] is None) == (plain[k] is None), k
+        if fused[k] is not None:
+            assert rel_err(fused[k], plain[k]) < 2e-5, k  # fp32 sums in another order
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ctx = O.upsample_video(params, video, expect_frames=T)
+    loss_o = F.cross_entropy(O.forward(params, dims, x, context=ctx), target)
+    loss_o.backward()
+    assert abs(loss_f - loss_o.item()) < 2e-6
+    for k, g in fused.items():
+        if params[k].grad is None:
+            assert g is None, k
+        else:
+            assert rel_err(g, params[k].grad) < 3e-4, k

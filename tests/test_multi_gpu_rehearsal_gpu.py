@@ -36,3 +36,13 @@ def test_bench_two_ranks_one_device():
     assert len(shas) == 2 and shas[0] == shas[1]
     assert tr["allreduce_path"] == "contiguous-span"
     assert tr["allreduce_floats"] >= 856320 - 64 * 64 - 64  # every used decoder parameter, one message
+    # BASELINE configs[2]/[3]: the video-conditioned workload, 8 clips of 32 frames per rank --
+    # decoder, context-conv AND video-encoder gradients as ONE message, one AdamW launch
+    t3 = out["train_step_config3"]
+    assert "error" not in t3, t3
+    assert t3["conditioned"] and t3["global_batch"] == 16 and t3["seq_len"] == 32000
+    assert t3["tokens_per_step"] == 2 * 8 * (32000 - 3072)
+    assert len(t3["param_sha256_per_rank"]) == 2 and t3["param_sha256_per_rank"][0] == t3["param_sha256_per_rank"][1]
+    assert t3["allreduce_path"] == "contiguous-span"
+    assert t3["allreduce_floats"] == 1491200  # every parameter of the model in one span
+    assert t3["optimizer_launches_per_step"] == 1

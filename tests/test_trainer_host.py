@@ -163,3 +163,71 @@ def test_data_parallel_gradient_exchange_gloo(tmp_path):
             continue
         assert torch.equal(g0, g1)
         assert torch.allclose(g0, (r[0]["local"][i] + r[1]["local"][i]) / 2, atol=1e-6)
+
+
+def _conditioned_layout_worker(rank: int, world: int, port: int, out_dir: str):
+    """BASELINE configs[3]'s gradient layout on two ranks: the conditioned decoder's gradients
+    in ops.decoder_param_names(with_context=True) order (NOT registration order: the context
+    convs come after the skip conv there, before the residual conv in the module) with the eight
+    video-encoder gradients behind them in one flat buffer -- what ops._run_backward +
+    VideoGradSlot hand to autograd -- must travel as ONE in-place all-reduce."""
+    import hashlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from movenet_amd.ops import VIDEO_PARAMS, decoder_param_names
+    from movenet_amd.parallel import FlatGradSync, init_distributed
+    from movenet_amd.wavenet import WaveNet
+    init_distributed("gloo", str(port))
+    torch.manual_seed(50 + rank)
+    model = WaveNet(layer_size=2, stack_size=2, input_channels=8, residual_channels=4, skip_channels=4)
+    sync = FlatGradSync(model.parameters(), world)
+    sync.broadcast_parameters(0)
+    lookup = dict(model.named_parameters())
+    L = 4
+    names = decoder_param_names(L, with_context=True) + list(VIDEO_PARAMS)
+    assert sorted(names) == sorted(lookup)  # the layout covers every parameter of the model
+    last = f"residual_conv_stack.conv_layers.{L - 1}.conv_residual."
+    flat = torch.zeros(sum(lookup[n].numel() for n in names))
+    gen = torch.Generator().manual_seed(900 + rank)
+    off = 0
+    for n in names:
+        p = lookup[n]
+        if not n.startswith(last):  # the last layer's residual conv gets no gradient: a gap
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            p.grad.copy_(torch.randn(p.shape, generator=gen))
+        off += p.numel()
+    local = {n: lookup[n].grad.clone() for n in names if lookup[n].grad is not None}
+    sent = sync.sync_gradients()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.grad is not None:
+                p.add_(p.grad, alpha=-0.1)
+    digest = hashlib.sha256(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy().tobytes()).hexdigest()
+    torch.save({"path": sync.last_path, "sent": sent, "digest": digest, "n": flat.numel(), "local": local,
+                "synced": {n: lookup[n].grad.clone() for n in local}}, os.path.join(out_dir, f"c{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_conditioned_gradient_layout_is_one_message_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_conditioned_layout_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"c{i}.pt", weights_only=True) for i in range(world)]
+    assert r[0]["path"] == r[1]["path"] == "contiguous-span"
+    assert r[0]["sent"] == r[1]["sent"] == r[0]["n"]  # the whole buffer, gap included, one message
+    assert r[0]["digest"] == r[1]["digest"]           # identical replicas after the step
+    for n, g in r[0]["synced"].items():
+        assert torch.allclose(g, (r[0]["local"][n] + r[1]["local"][n]) / 2, atol=1e-6), n
+
+
+def test_contiguous_span_rejects_overlap_and_foreign_storage():
+    from movenet_amd.parallel import contiguous_grad_span
+    a, b = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))
+    flat = torch.zeros(12)
+    a.grad, b.grad = flat[6:10], flat[0:4]           # decreasing order, a gap: fine
+    span = contiguous_grad_span([a, b])
+    assert span is not None and span.numel() == 10 and span.data_ptr() == flat.data_ptr()
+    a.grad, b.grad = flat[2:6], flat[0:4]            # overlapping views
+    assert contiguous_grad_span([a, b]) is None
+    a.grad, b.grad = flat[0:4], torch.zeros(4)       # two storages
+    assert contiguous_grad_span([a, b]) is None
