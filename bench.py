@@ -609,6 +609,7 @@ def main():
     # memory handed back fragmented is our reading, not verified)
     train, train3, fit = None, None, None
     if not args.no_train_leg:
+        from movenet_amd.ops import release_cached_buffers
         del gen
         torch.cuda.empty_cache()
         # both M2 workloads at every N: config 2 (audio only, BASELINE configs[1]) and config 3
@@ -626,6 +627,7 @@ def main():
                 train = line
             else:
                 train3 = line
+            release_cached_buffers()
             torch.cuda.empty_cache()
         if world == 1:
             try:
@@ -635,6 +637,7 @@ def main():
                 log(f"rank 0: Trainer.fit {fit['ms_per_step']:.2f} ms per step")
             except Exception as e:
                 fit = {"error": f"{type(e).__name__}: {e}"}
+            release_cached_buffers()
             torch.cuda.empty_cache()
 
     extras = None

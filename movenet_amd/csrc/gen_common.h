@@ -72,7 +72,8 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
 // ---- PIPE variant with fp16 operands (generate_pipe_h16.hip), C = K = 128 ----------------
 bool pipe_h16_ok(const mvn_dims *d);
 int pipe_h16_stages(const mvn_dims *d);
-int pipe_h16_max_batch(const mvn_dims *d);
+int pipe_h16_pipelines(const mvn_dims *d);  // pipelines co-resident on the chip
+int pipe_h16_max_batch(const mvn_dims *d);  // ... each serving up to h16::GMAX sequences in turn
 size_t pipe_h16_weights_floats(const mvn_dims *d);  // packed blob without the context section
 int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool has_ctx, hipStream_t s);
 int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_floats_total,
@@ -81,7 +82,8 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
 // ---- FOLD variant (generate_fold.hip), C = K = 64: residual 1x1 folded into the next layer
 bool fold_ok(const mvn_dims *d);
 int fold_stages(const mvn_dims *d);
-int fold_max_batch(const mvn_dims *d);
+int fold_pipelines(const mvn_dims *d);  // pipelines co-resident on the chip (one sequence each: the fastest step)
+int fold_max_batch(const mvn_dims *d);  // ... each serving up to fold::GMAX sequences in turn
 size_t fold_weights_floats(const mvn_dims *d);  // packed blob without the context section
 size_t fold_hand_floats(const mvn_dims *d, int batch);
 int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);

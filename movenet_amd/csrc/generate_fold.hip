@@ -61,6 +61,14 @@ constexpr int HEAD_F = W1_F + Q + W2_F + Q + WSL_F + C;
 constexpr int GRAN = 3 * C;                 // granules per inbox: xp | zl | sk
 // LDS floats: layer stage matrices + vectors; head stage the embedding tables (32768) + vectors
 constexpr int LDS_FLOATS = N_LDS_MAT * MAT_F + 1536 + 16;
+// r3, several sequences per pipeline ("rounds"): a stage is busy ~1.1 us of a 15 us step, so a
+// pipeline serves up to GMAX sequences in turn -- weights shared, one inbox per sequence and
+// stage, the LDS step vectors shared (they live within one turn).  What must survive from a
+// sequence's turn to its next is the past-tap part of its f/g sums (pf, pg: six floats per
+// channel), kept in LDS behind the vectors; the head keeps two class indices per sequence.
+constexpr int GMAX = 8;
+constexpr int PFS_F = 8;                    // floats per channel and sequence: pf0 pg0 pf1 pg1 | pf2 pg2 - -
+constexpr int LDS_FLOATS_MULTI = LDS_FLOATS + GMAX * C * PFS_F;
 }  // namespace fold
 
 // A thread's share of a matrix: 32 floats = 8 float4 of the packed order.  Two formats:
@@ -183,39 +191,10 @@ __device__ __forceinline__ float split_dot_lds(unsigned waddr, unsigned xaddr) {
   return t.x + t.y;
 }
 
-// The skip granule was sent a stage time ago: its load is issued at the START of the phase
-// that ends with its use (the round trip through L2 would otherwise sit on the skip lane, and
-// through it on the head); the spin loop is only the fallback.
-__device__ __forceinline__ u64 peek_granule(const u64 *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One granule of the skip lane, polled by the lane that owns the channel (off the chain: it was
-// sent a whole stage time ago).  A time-out raises the status word; the caller carries on with
-// the stale value (the host sees the word).
-__device__ __forceinline__ float wait_granule(const u64 *p, unsigned epoch, unsigned *err) {
-  for (unsigned spins = 1;; ++spins) {
-    unsigned lo, hi;
-    {
-      typedef unsigned v2u __attribute__((ext_vector_type(2)));
-      v2u g;
-      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
-      lo = g.x;
-      hi = g.y;
-    }
-    if (hi == epoch) return __uint_as_float(lo);
-    if ((spins & 255u) == 0) {
-      const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return __uint_as_float(lo);
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, unsigned *err, int NS, int nb) {
+// MULTI = false: one sequence per pipeline (nseq == nb), the form every config-2 figure up to
+// batch 16 is measured on.  MULTI = true: pipeline b serves sequences b, b + nb, b + 2 nb, ... < nseq.
+template <bool MULTI>
+__global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, unsigned *err, int NS, int nb, int nseq) {
   using namespace fold;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,9 +206,12 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // sticky status
   const int L = a.L;
   const int s_next = s + 1 == NS ? 0 : s + 1;
+  const int G = MULTI ? (nseq - b + nb - 1) / nb : 1;  // sequences of this pipeline
+  int bq = b;                                           // the sequence whose turn it is
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
   u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
   int *iflag = (int *)(smem + LDS_FLOATS - 16);  // [0] ok flag, [3] fast-edge flag
+  float *pfs = smem + LDS_FLOATS;                // MULTI: [GMAX][C][PFS_F] (layer stages), head: indices
   bool fast_edge = false;
   {
     unsigned *xcc = err + 16;  // [nb * NS] words, zeroed by the launch's memset
@@ -272,6 +254,14 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
     u64 *ob = outbox + c;                // granules of this lane's channel: xp' | zl' (+ C) | sk' (+ 2C)
     const u64 *ibs = inbox + 2 * C + c;
     float *ring = a.state + (size_t)b * a.state_per_seq;
+    auto bind = [&](int g) {  // MULTI: the pointers of sequence b + g nb
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      ob = outbox + c;
+      ibs = inbox + 2 * C + c;
+      ring = a.state + (size_t)bq * a.state_per_seq;
+    };
     const float *sec = a.w + EMB_F + (size_t)s * STAGE_F;
     const float *vecs = sec + N_MAT * MAT_F;
 
@@ -308,7 +298,22 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
     // entries step tn needs (helper lead lanes), then the past-tap half of step tn's f/g sums
     // (chain waves, matrices streamed from LDS).  Addresses are rebuilt here behind an
     // optimisation fence (the chain needs the registers, this code has slack).
-    auto precompute = [&](int tn, bool push) {
+    // MULTI: a turn's service time is what bounds the step beyond ~5 sequences per pipeline, and
+    // most of it was the round trip of these pops (128 sequences' queues are 100 MB: MALL / HBM,
+    // not L2).  The entries step tn needs were pushed at least two steps ago (dilation 1 takes
+    // this step's value instead), so they are requested at the TOP of the turn and arrive under
+    // the wait for the inbox and the chain.
+    float popv[LPS] = {0.f, 0.f, 0.f};
+    auto prefetch_pops = [&](int tn) {
+      if (MULTI && !chain && lead) {
+        int cq = c;
+        asm volatile("" : "+v"(cq));
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) popv[j] = ring_load(ring + doff[j] + cq + (tn & dmask[j]) * C);
+      }
+    };
+    auto precompute = [&](int tn, bool push, bool popped) {
       int tq = t;
       asm volatile("" : "+v"(tq));
       const int cq = tq >> 2, kk = tq & 3;
@@ -318,11 +323,12 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
           if (j < nl) {
             float *base = ring + doff[j] + cq;
             if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
-            const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
+            const float pv = (push && dmask[j] == 0) ? xs[j]
+                             : (MULTI && popped) ? popv[j] : ring_load(base + (tn & dmask[j]) * C);
             vec[O_PAST + j * C + cq] = pv;
           }
       }
-      if (a.ctx_tm && chain && tq < C) vec[O_CTX + tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
+      if (a.ctx_tm && chain && tq < C) vec[O_CTX + tq] = a.ctx_tm[(size_t)bq * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
       if (chain) {
         const unsigned wm = lds_addr(lmat) + 16u * tq, xq = lds_addr(vec) + 4u * (O_PAST + KPER * kk);
@@ -348,10 +354,42 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
         }
       }
     };
+    // MULTI: a sequence's pf / pg between its turns (lead lanes of the chain waves write, the four
+    // lanes of a channel read the same 32 bytes)
+    auto save_pf = [&](int g) {
+      if (MULTI && chain && lead) {
+        float *q = pfs + ((size_t)g * C + c) * PFS_F;
+        *(f4 *)q = f4{pf[0], pg[0], pf[1], pg[1]};
+        *(v2f *)(q + 4) = v2f{pf[2], pg[2]};
+      }
+    };
+    auto load_pf = [&](int g) {
+      if (MULTI && chain) {
+        const float *q = pfs + ((size_t)g * C + c) * PFS_F;
+        const f4 v = *(const f4 *)q;
+        const v2f w = *(const v2f *)(q + 4);
+        pf[0] = v.x; pg[0] = v.y; pf[1] = v.z; pg[1] = v.w; pf[2] = w.x; pg[2] = w.y;
+      }
+    };
     __syncthreads();
-    precompute(a.t_begin, false);
+    if (MULTI) {
+      for (int g = 0; g < G; ++g) {
+        bind(g);
+        precompute(a.t_begin, false, false);
+        save_pf(g);
+        __syncthreads();  // the chain waves have read this sequence's popped entries: the next one's may land
+      }
+    } else {
+      precompute(a.t_begin, false, false);
+    }
 
-    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) {
+        bind(g);
+        if (ts + 1 < a.t_end) prefetch_pops(ts + 1);
+      }
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       if (wave == 0) {
         // 2C granules: lane i takes 2i, 2i + 1 (xp for i < 32, zl above) with one 16-byte load
@@ -366,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
+      load_pf(g);
       float xv = 0.f;  // helper lead lanes: the explicit stream
       MVN_FINE(b, s, ts - a.t_begin, 0, 0);
       // ---- phase 0
@@ -485,9 +524,13 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
       lds_barrier();  // iflag and the step's LDS vectors are settled for everyone
-      if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      if (iflag[0] == 0) {  // hand-off timed out (checked after the step: off the chain)
+        alive = false;
+        break;
+      }
       if (ts + 1 < a.t_end) {
-        precompute(ts + 1, true);
+        precompute(ts + 1, true, true);
+        save_pf(g);
       } else if (!chain && lead) {
         // last step of the launch: push only (the next launch pops in its prologue)
         int cq = c;
@@ -515,6 +558,13 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
     const f4 *WSp = (const f4 *)(hw + W1_F + Q + W2_F + Q);
     const float *bsl = hw + W1_F + Q + W2_F + Q + WSL_F;
     int32_t *samples = a.samples + (size_t)b * a.stride;
+    int *hidx = (int *)pfs;  // MULTI: [GMAX][2] = {idx_cur, idx_prev} of each sequence between its turns
+    auto bind = [&](int g) {
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      samples = a.samples + (size_t)bq * a.stride;
+    };
 
     // last layer's skip 1x1: thread (cs = tid >> 3, q8 = tid & 7), 8 inputs;
     // conv1: thread (o1 = tid >> 1, q1 = tid & 1), 32 inputs; conv2: thread (og = tid >> 3,
@@ -544,14 +594,31 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       put_granule(outbox + C + lane, ep, 0.f, fast_edge);
       put_granule(outbox + 2 * C + lane, ep, 0.f, fast_edge);
     };
-    if (wave == 0) {
-      idx_cur = samples[a.t_begin];
-      idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
-      if (a.t_begin < a.t_end) send_h0(1u);
-      MVN_STAMP(b, s, 0, 1);
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) bind(g);
+      if (wave == 0) {
+        idx_cur = samples[a.t_begin];
+        idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
+        if (a.t_begin < a.t_end) send_h0(1u);
+        MVN_STAMP(b, s, 0, 1);
+        if (MULTI && lane == 0) {
+          hidx[2 * g] = idx_cur;
+          hidx[2 * g + 1] = idx_prev;
+        }
+      }
     }
+    if (MULTI) __syncthreads();
 
-    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) {
+        bind(g);
+        if (wave == 0) {  // (written by this wave's lane 0 a whole round ago)
+          idx_cur = hidx[2 * g];
+          idx_prev = hidx[2 * g + 1];
+        }
+      }
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       const int u = ts + 1;
       const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
@@ -561,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
       // keeps it from being sunk to its use behind the head's barriers)
       float uni = 0.f;
       if (wave == 0 && a.temperature > 0.f) {
-        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b);
+        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)bq);
         asm volatile("" : "+v"(uni));
       }
       if (wave == 0) {
@@ -623,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
           const f4 lv = ((const f4 *)lgb)[lane];
           const float lg[4] = {lv.x, lv.y, lv.z, lv.w};
           if (a.logits_out && u >= a.logits_t0)
-            ((f4 *)(a.logits_out + ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
+            ((f4 *)(a.logits_out + ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
           const int pick = choose_class(lg, a.temperature, uni, lane, Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
@@ -631,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
           if (ts + 1 < a.t_end) send_h0(epoch + 1);
           MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
           if (lane == 0) {
-            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
+            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)bq * a.n_total + u] = pick;
             if (u >= a.n_given) samples[u] = pick;
           }
         } else {
@@ -640,8 +707,15 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
           if (ts + 1 < a.t_end) send_h0(epoch + 1);
           MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
         }
+        if (MULTI && lane == 0) {
+          hidx[2 * g] = idx_cur;
+          hidx[2 * g + 1] = idx_prev;
+        }
       }
-      if (iflag[0] == 0) break;  // hand-off timed out
+      if (iflag[0] == 0) {  // hand-off timed out
+        alive = false;
+        break;
+      }
     }
   }
 }
@@ -757,7 +831,8 @@ bool fold_ok(const mvn_dims *d) {
          n_layers(d) >= 1 && (n_layers(d) + fold::LPS - 1) / fold::LPS + 1 <= PIPE_XCD_CUS;
 }
 int fold_stages(const mvn_dims *d) { return (n_layers(d) + fold::LPS - 1) / fold::LPS + 1; }
-int fold_max_batch(const mvn_dims *d) { return 8 * (PIPE_XCD_CUS / fold_stages(d)); }
+int fold_pipelines(const mvn_dims *d) { return 8 * (PIPE_XCD_CUS / fold_stages(d)); }  // co-resident pipelines
+int fold_max_batch(const mvn_dims *d) { return fold::GMAX * fold_pipelines(d); }         // GMAX sequences each
 size_t fold_weights_floats(const mvn_dims *d) {
   return (size_t)fold::EMB_F + (size_t)(fold_stages(d) - 1) * fold::STAGE_F + fold::HEAD_F;
 }
@@ -797,14 +872,19 @@ int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t
 }
 
 // context section: the PIPE variant's per-layer layout (same thread mapping), packed by it
+//
+// Up to fold_pipelines(d) sequences: one sequence per pipeline (gen_fold_kernel<false>).  More:
+// the pipelines serve ceil(batch / pipelines) sequences each in turn (gen_fold_kernel<true>).
 int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_floats_total,
                 size_t status_offset_floats, hipStream_t s) {
   using namespace fold;
   int NS = fold_stages(d);
-  const void *fn = (const void *)gen_fold_kernel;
+  const int pipes = std::min(batch, fold_pipelines(d));
+  const bool multi = batch > pipes;
+  const void *fn = multi ? (const void *)gen_fold_kernel<true> : (const void *)gen_fold_kernel<false>;
   int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_fold)");
   if (rc) return rc;
-  const size_t lds_bytes = LDS_FLOATS * sizeof(float);
+  const size_t lds_bytes = (multi ? LDS_FLOATS_MULTI : LDS_FLOATS) * sizeof(float);
   int dev = 0, cus = 0, per_cu = 0, coop = 0;
   if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||
       check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute(CUs)") ||
@@ -813,10 +893,10 @@ int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
       check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, lds_bytes),
                 "hipOccupancyMaxActiveBlocksPerMultiprocessor(gen_fold)"))
     return MVN_ERR_LAUNCH;
-  const int slots = (batch + 7) / 8 * NS;
+  const int slots = (pipes + 7) / 8 * NS;
   if (cus < 8 * PIPE_XCD_CUS || batch > fold_max_batch(d) || per_cu < 1 || slots * 8 > per_cu * cus) {
-    set_error("FOLD variant: %d stages per sequence, at most %d sequences co-resident on %d CUs (batch %d "
-              "asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : fold_max_batch(d), cus, batch);
+    set_error("FOLD variant: %d stages per pipeline, %d pipelines of at most %d sequences each on %d CUs (batch %d "
+              "asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : fold_pipelines(d), GMAX, cus, batch);
     return MVN_ERR_UNSUPPORTED;
   }
   // hand-off area layout of the generator state: [granules ...][16 flag words at
@@ -835,13 +915,16 @@ int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
   if (rc) return rc;
   u64 *gran = (u64 *)hand;
   GenArgs args = a;
-  int nb = batch;
+  int nb = pipes, nseq = batch;
   if (coop && pipe_cooperative_launch()) {
-    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
+    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb, (void *)&nseq};
     return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)lds_bytes, s),
                      "mvn_generate(fold, cooperative launch)");
   }
-  hipLaunchKernelGGL(gen_fold_kernel, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb);
+  if (multi)
+    hipLaunchKernelGGL(gen_fold_kernel<true>, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb, nseq);
+  else
+    hipLaunchKernelGGL(gen_fold_kernel<false>, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb, nseq);
   return check_hip(hipGetLastError(), "mvn_generate(fold)");
 }
 

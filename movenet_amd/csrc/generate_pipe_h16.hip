@@ -19,6 +19,7 @@
 // partial sums, biases, gating, the embedding rows (a gather, no product), the dilation
 // queues in HBM/L2, logits and the double softmax.
 // Tolerance against the fp32 path: DESIGN.md section 2 / tests/test_fp16_gpu.py.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -43,10 +44,17 @@ constexpr int CTX_LAYER_F = MAT_F + 2 * C;
 constexpr int EMB_F = 2 * Q * C;    // fp32 tables
 constexpr int W1_F = Q * C / 2, W2_F = Q * Q / 2;
 constexpr int HEAD_F = W1_F + Q + W2_F + Q;
-constexpr int GRAN = 2 * C, GL = GRAN / 64;
+constexpr int GRAN = 2 * C;         // granules per inbox: C residual stream | C running skip sum
+constexpr int GL = C / 64;          // the chain polls the residual granules only: one 16-byte load per lane
 constexpr int W1NV = (C / 2) / 8;   // conv1: 2 threads per row, 64 inputs each = 8 vectors
 // LDS bytes: layer stage LPS * 64 KB of past-tap weights + vectors; head stage 64 KB of conv1
 constexpr int LDS_BYTES = LPS * MAT_H * 2 + 8192;
+// r3, several sequences per pipeline (as gen_fold_kernel<true>): a pipeline serves up to GMAX
+// sequences in turn; what survives from a sequence's turn to its next is the past-tap part of its
+// f/g sums (pf, pg of the LPS layers: four floats per channel), kept in LDS behind the vectors
+constexpr int GMAX = 8;
+constexpr int PFS_F = 2 * LPS;      // floats per channel and sequence
+constexpr int LDS_BYTES_MULTI = LDS_BYTES + GMAX * C * PFS_F * 4;
 }  // namespace h16
 
 __device__ __forceinline__ float dot8(const h8 w, const h8 x, float acc) {
@@ -107,8 +115,11 @@ __device__ __forceinline__ float dot_stream_h(const h8 *wsrc, int stride, int id
 }
 __device__ __forceinline__ float pair_sum(float v) { return v + dpp_mov<DPP_XOR1>(v); }
 
+// MULTI = false: one sequence per pipeline (nseq == nb).  MULTI = true: pipeline b serves sequences
+// b, b + nb, b + 2 nb, ... < nseq in turn.
+template <bool MULTI>
 __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *hand, unsigned *err, int NS,
-                                                             int nb) {
+                                                             int nb, int nseq) {
   using namespace h16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -129,9 +140,12 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // sticky status
   const int L = a.L;
   const int s_next = s + 1 == NS ? 0 : s + 1;
+  const int G = MULTI ? (nseq - b + nb - 1) / nb : 1;  // sequences of this pipeline
+  int bq = b;                                           // the sequence whose turn it is
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
   u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
   int *iflag = (int *)(smem_b + LDS_BYTES - 64);  // [0] ok flag, [3] fast-edge flag
+  float *pfs = (float *)(smem_b + LDS_BYTES);     // MULTI: [GMAX][C][PFS_F] (layer stages), head: indices
   bool fast_edge = false;
   {
     unsigned *xcc = err + 16;
@@ -158,12 +172,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
     const bool lead = kq == 0;
     h8 *wp = (h8 *)smem_b;                                   // [LPS][2*NV][256] h8: past-tap f|g weights
     float *cur = (float *)(smem_b + LPS * MAT_H * 2);        // [C] residual stream (fp32)
-    float *skin = cur + C;                                   // [C] running skip sum as received
-    _Float16 *curh = (_Float16 *)(skin + C);                 // [C] the stream as the products' operand
+    _Float16 *curh = (_Float16 *)(cur + 2 * C);              // [C] the stream as the products' operand
+    // r3: the running skip sum travels on a lane of its own (as in gen_fold_kernel): the chain waits
+    // for the C residual granules only -- ONE 16-byte poll per lane through poll16 -- and the lane
+    // that owns a channel fetches its skip granule off the chain and adds it when the stage hands on
+    const u64 *skbox = inbox + C + c;  // (rebound per turn when MULTI)
     _Float16 *zbh = curh + C;                                // [C] gated activation
     _Float16 *pasth = zbh + C;                               // [LPS][C] popped queue entries
     _Float16 *ctxh = pasth + LPS * C;                        // [C] context column
     float *ring = a.state + (size_t)b * a.state_per_seq;
+    auto bind = [&](int g) {  // MULTI: the pointers of sequence b + g nb
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      skbox = inbox + C + c;
+      ring = a.state + (size_t)bq * a.state_per_seq;
+    };
 
     h8 wa[LPS][NV], wb[LPS][NV];  // FG: f_c | g_c current-tap rows; RS: res_c | skip_c
     float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
@@ -220,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           }
       }
       if (a.ctx_tm && fg_group && tq < C)
-        ctxh[tq] = (_Float16)a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
+        ctxh[tq] = (_Float16)a.ctx_tm[(size_t)bq * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
       if (fg_group) {
 #pragma unroll
@@ -239,27 +263,51 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           }
       }
     };
+    // MULTI: a sequence's pf / pg between its turns (FG lead lanes write, both lanes of a channel read)
+    auto save_pf = [&](int g) {
+      if (MULTI && fg_group && lead) *(f4 *)(pfs + ((size_t)g * C + c) * PFS_F) = f4{pf[0], pg[0], pf[1], pg[1]};
+    };
+    auto load_pf = [&](int g) {
+      if (MULTI && fg_group) {
+        const f4 v = *(const f4 *)(pfs + ((size_t)g * C + c) * PFS_F);
+        pf[0] = v.x; pg[0] = v.y; pf[1] = v.z; pg[1] = v.w;
+      }
+    };
+    static_assert(LPS == 2, "save_pf / load_pf move two layers' sums as one float4");
     __syncthreads();
-    precompute(a.t_begin, false);
+    if (MULTI) {
+      for (int g = 0; g < G; ++g) {
+        bind(g);
+        precompute(a.t_begin, false);
+        save_pf(g);
+        __syncthreads();  // the FG waves have read this sequence's popped entries: the next one's may land
+      }
+    } else {
+      precompute(a.t_begin, false);
+    }
 
-    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) bind(g);
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       if (wave == 0) {
         float v[GL];
-        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
+        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);  // the C residual granules
         if (ok) {
-          // granules 0..C-1 residual stream, C..2C-1 running skip sum
           cur[2 * lane] = v[0];
           cur[2 * lane + 1] = v[1];
           *(h2 *)(curh + 2 * lane) = h2{(_Float16)v[0], (_Float16)v[1]};
-          skin[2 * lane] = v[GL - 2];
-          skin[2 * lane + 1] = v[GL - 1];
         }
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
-      float skipacc = (!fg_group && lead) ? skin[c] : 0.f;
+      load_pf(g);
+      // skip lane: the granule was sent with the residual ones; its load is issued here and used
+      // when the stage hands on (the spin loop is only the fallback)
+      const u64 sk_peek = (!fg_group && lead) ? peek_granule(skbox) : 0;
+      float skipacc = 0.f;
 #pragma unroll
       for (int j = 0; j < LPS; ++j)
         if (j < nl) {
@@ -289,16 +337,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
               if (j == nl - 1) {
                 // the stage's last layer: hand the activation on before anything else
                 put_granule(outbox + c, epoch, outv, fast_edge);
-                put_granule(outbox + C + c, epoch, skipacc, fast_edge);
+                const float skin = (unsigned)(sk_peek >> 32) == epoch ? __uint_as_float((unsigned)sk_peek)
+                                                                      : wait_granule(skbox, epoch, err);
+                put_granule(outbox + C + c, epoch, skin + skipacc, fast_edge);
               }
             }
           }
           lds_barrier();
         }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
-      if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      if (iflag[0] == 0) {  // hand-off timed out (checked after the step: off the chain)
+        alive = false;
+        break;
+      }
       if (ts + 1 < a.t_end) {
         precompute(ts + 1, true);
+        save_pf(g);
       } else if (!fg_group && lead) {
         // last step of the launch: push only (the next launch pops in its prologue)
 #pragma unroll
@@ -320,6 +374,13 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
     const h8 *W1p = (const h8 *)hw, *W2p = (const h8 *)(hw + W1_F + Q);
     const float *b1 = hw + W1_F, *b2 = hw + W1_F + Q + W2_F;
     int32_t *samples = a.samples + (size_t)b * a.stride;
+    int *hidx = (int *)pfs;  // MULTI: [GMAX][2] = {idx_cur, idx_prev} of each sequence between its turns
+    auto bind = [&](int g) {
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      samples = a.samples + (size_t)bq * a.stride;
+    };
 
     // conv1: thread (o1 = tid>>1, q1 = tid&1), 64 inputs; conv2: thread (og = tid>>3, q2 = tid&7),
     // 4 outputs x 32 inputs
@@ -346,14 +407,31 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
         put_granule(outbox + C + ch, ep, 0.f, fast_edge);
       }
     };
-    if (wave == 0) {
-      idx_cur = samples[a.t_begin];
-      idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
-      if (a.t_begin < a.t_end) send_h0(1u);
-      MVN_STAMP(b, s, 0, 1);
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) bind(g);
+      if (wave == 0) {
+        idx_cur = samples[a.t_begin];
+        idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
+        if (a.t_begin < a.t_end) send_h0(1u);
+        MVN_STAMP(b, s, 0, 1);
+        if (MULTI && lane == 0) {
+          hidx[2 * g] = idx_cur;
+          hidx[2 * g + 1] = idx_prev;
+        }
+      }
     }
+    if (MULTI) __syncthreads();
 
-    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) {
+        bind(g);
+        if (wave == 0) {  // (written by this wave's lane 0 a whole round ago)
+          idx_cur = hidx[2 * g];
+          idx_prev = hidx[2 * g + 1];
+        }
+      }
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       const int u = ts + 1;
       const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
@@ -363,15 +441,14 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       // keeps it from being sunk to its use behind the head's barriers)
       float uni = 0.f;
       if (wave == 0 && a.temperature > 0.f) {
-        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b);
+        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)bq);
         asm volatile("" : "+v"(uni));
       }
       if (wave == 0) {
         if (u < a.n_given) next_idx = samples[u];  // prompt / teacher forcing
         float v[GL];
-        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);
-        if (ok)  // only the skip sum (granules C..2C-1) feeds the head
-          *(h2 *)(a0h + 2 * lane) = h2{(_Float16)leaky(v[GL - 2]), (_Float16)leaky(v[GL - 1])};
+        const bool ok = wait_inbox<GL>(inbox + C, epoch, err, v);  // only the skip sum feeds the head
+        if (ok) *(h2 *)(a0h + 2 * lane) = h2{(_Float16)leaky(v[0]), (_Float16)leaky(v[1])};
         if (lane == 0) iflag[0] = ok ? 1 : 0;
       }
       lds_barrier();
@@ -406,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           const f4 lv = ((const f4 *)lgb)[lane];
           const float lg[4] = {lv.x, lv.y, lv.z, lv.w};
           if (a.logits_out && u >= a.logits_t0)
-            ((f4 *)(a.logits_out + ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
+            ((f4 *)(a.logits_out + ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
           const int pick = choose_class(lg, a.temperature, uni, lane, Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
@@ -414,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           if (ts + 1 < a.t_end) send_h0(epoch + 1);
           MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
           if (lane == 0) {
-            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
+            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)bq * a.n_total + u] = pick;
             if (u >= a.n_given) samples[u] = pick;
           }
         } else {
@@ -423,8 +500,15 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           if (ts + 1 < a.t_end) send_h0(epoch + 1);
           MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
         }
+        if (MULTI && lane == 0) {
+          hidx[2 * g] = idx_cur;
+          hidx[2 * g + 1] = idx_prev;
+        }
       }
-      if (iflag[0] == 0) break;  // hand-off timed out
+      if (iflag[0] == 0) {  // hand-off timed out
+        alive = false;
+        break;
+      }
     }
   }
 }
@@ -503,10 +587,11 @@ bool pipe_h16_ok(const mvn_dims *d) {
          n_layers(d) >= 1;
 }
 int pipe_h16_stages(const mvn_dims *d) { return (n_layers(d) + h16::LPS - 1) / h16::LPS + 1; }
-int pipe_h16_max_batch(const mvn_dims *d) {
+int pipe_h16_pipelines(const mvn_dims *d) {  // co-resident pipelines
   const int NS = pipe_h16_stages(d);
   return NS <= PIPE_XCD_CUS ? 8 * (PIPE_XCD_CUS / NS) : 8 / ((NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS);
 }
+int pipe_h16_max_batch(const mvn_dims *d) { return h16::GMAX * pipe_h16_pipelines(d); }  // GMAX sequences each
 size_t pipe_h16_weights_floats(const mvn_dims *d) {
   return (size_t)h16::EMB_F + (size_t)n_layers(d) * h16::LAYER_F + h16::HEAD_F;
 }
@@ -539,8 +624,11 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
                     size_t status_off, hipStream_t s) {
   using namespace h16;
   int NS = pipe_h16_stages(d);
+  const int pipes = std::min(batch, pipe_h16_pipelines(d));
+  const bool multi = batch > pipes;
   int dev = 0, cus = 0, per_cu = 0, coop = 0;
-  const void *fn = (const void *)gen_pipe_h16_kernel;
+  const void *fn = multi ? (const void *)gen_pipe_h16_kernel<true> : (const void *)gen_pipe_h16_kernel<false>;
+  const int lds_bytes = multi ? LDS_BYTES_MULTI : LDS_BYTES;
   int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_pipe_h16)");
   if (rc) return rc;
   if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||
@@ -548,14 +636,14 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
                 "hipDeviceGetAttribute(CUs)") ||
       check_hip(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev),
                 "hipDeviceGetAttribute(cooperative)") ||
-      check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, LDS_BYTES),
+      check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, lds_bytes),
                 "hipOccupancyMaxActiveBlocksPerMultiprocessor(gen_pipe_h16)"))
     return MVN_ERR_LAUNCH;
   const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS;
-  const int slots = NS <= PIPE_XCD_CUS ? (batch + 7) / 8 * NS : (NS + XS - 1) / XS;
+  const int slots = NS <= PIPE_XCD_CUS ? (pipes + 7) / 8 * NS : (NS + XS - 1) / XS;
   if (cus < 8 * PIPE_XCD_CUS || batch > pipe_h16_max_batch(d) || per_cu < 1 || slots * 8 > per_cu * cus) {
-    set_error("PIPE_F16 variant: %d stages per sequence, at most %d sequences co-resident on %d CUs "
-              "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_h16_max_batch(d), cus, batch);
+    set_error("PIPE_F16 variant: %d stages per pipeline, %d pipelines of at most %d sequences each on %d CUs "
+              "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_h16_pipelines(d), GMAX, cus, batch);
     return MVN_ERR_UNSUPPORTED;
   }
   if ((size_t)batch * NS * GRAN * 2 > status_off || status_off + 16 + (size_t)batch * NS > hand_total) {
@@ -571,13 +659,16 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
   if (rc) return rc;
   u64 *gran = (u64 *)hand;
   GenArgs args = a;
-  int nb = batch;
+  int nb = pipes, nseq = batch;
   if (coop && pipe_cooperative_launch()) {
-    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
-    return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)LDS_BYTES, s),
+    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb, (void *)&nseq};
+    return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)lds_bytes, s),
                      "mvn_generate(pipe_f16, cooperative launch)");
   }
-  hipLaunchKernelGGL(gen_pipe_h16_kernel, dim3(slots * 8), dim3(NT), LDS_BYTES, s, args, gran, err, NS, nb);
+  if (multi)
+    hipLaunchKernelGGL(gen_pipe_h16_kernel<true>, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb, nseq);
+  else
+    hipLaunchKernelGGL(gen_pipe_h16_kernel<false>, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb, nseq);
   return check_hip(hipGetLastError(), "mvn_generate(pipe_f16)");
 }
 

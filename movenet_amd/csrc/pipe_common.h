@@ -146,6 +146,38 @@ __device__ __forceinline__ bool wait16(const u64 *p, unsigned epoch, unsigned *e
   }
 }
 
+// The skip granule was sent a stage time ago: its load is issued at the START of the phase
+// that ends with its use (the round trip through L2 would otherwise sit on the skip lane, and
+// through it on the head); the spin loop is only the fallback.
+__device__ __forceinline__ u64 peek_granule(const u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One granule of the skip lane, polled by the lane that owns the channel (off the chain: it was
+// sent a whole stage time ago).  A time-out raises the status word; the caller carries on with
+// the stale value (the host sees the word).
+__device__ __forceinline__ float wait_granule(const u64 *p, unsigned epoch, unsigned *err) {
+  for (unsigned spins = 1;; ++spins) {
+    unsigned lo, hi;
+    {
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      v2u g;
+      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+      lo = g.x;
+      hi = g.y;
+    }
+    if (hi == epoch) return __uint_as_float(lo);
+    if ((spins & 255u) == 0) {
+      const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || spins > PIPE_SPIN_LIMIT) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __uint_as_float(lo);
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 template <int GL>
 __device__ __forceinline__ bool wait_inbox(const u64 *in, unsigned epoch, unsigned *err,
                                            float (&v)[GL]) {

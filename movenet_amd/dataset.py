@@ -117,23 +117,64 @@ class SyntheticLoader:
                 vr = np.random.default_rng(self.seed * 7919 + 4321 + ids[0])
                 video = torch.from_numpy(
                     vr.random((len(ids), self.frames // 1000, 64, 64, 1), dtype=np.float32))
-                if self.device is not None:
-                    video = video.to(self.device, non_blocking=True)
+                if self.device is not None and self.device.type == "cuda":
+                    video = _to_device_async(video, self.device)
             yield Batch(audio, video, ["synthetic"] * len(ids),
                         [f"synthetic://{i}" for i in ids],
                         [dict(video_fps=0.0, audio_fps=float(self.frames) / 10.0)] * len(ids))
 
 
+_FEED_STREAMS: dict = {}
+
+
+def _feed_stream(device: torch.device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _FEED_STREAMS.get(key)
+    if st is None:
+        st = _FEED_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _one_hot_on_device(idx: torch.Tensor, Q: int, device: torch.device) -> torch.Tensor:
-    """(B,T) int64 host indices -> (B,Q,T) fp32 one-hot on ``device`` through the C ABI."""
+    """(B,T) int64 host indices -> (B,Q,T) fp32 one-hot on ``device`` through the C ABI.
+
+    The indices (4 bytes per sample) cross PCIe from pinned memory on a FEED stream of their own;
+    the consumer's stream waits for that copy's event and expands them itself (mvn_index_to_onehot:
+    ~70 us for 16 x 256 x 16000).  A copy from pageable memory on the training stream would make the
+    host wait until everything queued there -- the whole previous step -- has run, i.e. the loader
+    would serialise host and GPU.  The large one-hot tensor is allocated on the TRAINING stream: a
+    block handed from one stream's pool to another is not reusable until the other stream's work
+    on it has been seen to finish, and the allocator then asks the driver for a new 262 MB block
+    every step."""
     from . import _native as N
     B, T = idx.shape
+    main = torch.cuda.current_stream(device)
+    feed = _feed_stream(device)
+    pinned = idx.to(torch.int32).pin_memory()
     with torch.cuda.device(device):
-        d_idx = idx.to(torch.int32).to(device, non_blocking=True)
+        with torch.cuda.stream(feed):
+            d_idx = pinned.to(device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(feed)
+        main.wait_event(ready)
+        d_idx.record_stream(main)
         out = torch.empty(B, Q, T, dtype=torch.float32, device=device)
         N.check(N.lib().mvn_index_to_onehot(d_idx.data_ptr(), d_idx.stride(0), out.data_ptr(), B, Q, T,
-                                            torch.cuda.current_stream(device).cuda_stream),
-                "mvn_index_to_onehot")
+                                            main.cuda_stream), "mvn_index_to_onehot")
+    return out
+
+
+def _to_device_async(x: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """Host tensor -> device through pinned memory on the feed stream (see _one_hot_on_device)."""
+    main = torch.cuda.current_stream(device)
+    feed = _feed_stream(device)
+    pinned = x.pin_memory()
+    with torch.cuda.device(device), torch.cuda.stream(feed):
+        out = pinned.to(device, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record(feed)
+    main.wait_event(ready)
+    out.record_stream(main)
     return out
 
 

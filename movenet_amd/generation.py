@@ -229,12 +229,29 @@ class RingGenerator:
         return choices, logits
 
 
-# measured microseconds per generated sample-step of ONE launch (any number of co-resident
-# sequences up to the variant's limit); keys: (C, variant)
+# measured microseconds per generated sample-step of ONE launch; keys:
+# (C, variant).  PIPE: any number of co-resident sequences up to the variant's limit.  FOLD: its
+# 16 pipelines (config 2) serve ceil(n / 16) sequences each in turn (r3): 14.8 us for one round,
+# ~15.5 up to five, then the stages' service time per turn (~3.3 us) bounds the step.
 _T_STEP_US = {(64, N.GEN_FOLD): 15.0, (64, N.GEN_PIPE): 17.5, (128, N.GEN_PIPE): 79.0}
+_FOLD_ROUNDS = 8          # fold::GMAX of csrc/generate_fold.hip
+_FOLD_TURN_US = 3.3
 # ... and of the best kernel that takes EVERY sequence in one launch; keys: (C, conditioned):
 # STREAM at C=64 without conditioning, GENERIC otherwise
 _T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128, True): 490.0}
+
+
+def _launch_step_us(dims, variant: int, n: int):
+    """Modelled step time (us) of ONE launch of ``variant`` holding ``n`` sequences, or None."""
+    C = dims.residual_channels
+    t = _T_STEP_US.get((C, variant))
+    if t is None:
+        return None
+    if variant == N.GEN_FOLD:
+        pipes = max(1, max_pipe_batch(dims, variant) // _FOLD_ROUNDS)
+        rounds = -(-n // pipes)
+        return t if rounds <= 1 else max(t + 0.5, _FOLD_TURN_US * rounds)
+    return t
 
 
 def auto_plan(dims, batch: int, has_context: bool):
@@ -242,12 +259,11 @@ def auto_plan(dims, batch: int, has_context: bool):
     ``("single", 0, variant)`` for one launch or ``("grouped", group, variant)`` for groups of
     ``group`` sequences taking turns on the pipelines of a pipelined variant.
 
-    Chosen on measured per-step cost: a pipelined step costs the same for 1..group sequences,
-    so n groups cost n x t per step of all of them, against ONE launch of the best kernel that
-    holds every sequence (C=K=64: FOLD 15.0 us for up to 16, PIPE 17.5 us for up to 24, STREAM
-    78 us / conditioned GENERIC ~0.3 ms for any number; C=K=128: PIPE 79 us for up to 4,
-    GENERIC 490 us).  Config 2: 1-16 FOLD, 17-24 PIPE, 25-32 two FOLD groups, 33-96 PIPE
-    groups, STREAM beyond (conditioned: PIPE groups up to 16 of them)."""
+    Chosen on measured per-step cost.  C=K=64: ONE FOLD launch holds up to 128 sequences (16
+    pipelines x 8 rounds: 14.8 us for 16, 15.5 for 64, 26 for 128); beyond that balanced groups
+    of FOLD launches take turns as long as they beat the one-launch kernels (STREAM 78 us /
+    conditioned GENERIC ~0.3 ms for any number).  C=K=128: PIPE 79 us for up to 4, groups of 4
+    up to 24, GENERIC 490 us beyond."""
     lib = N.lib()
     single = N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
     if single in N.PIPE_VARIANTS:
@@ -255,10 +271,12 @@ def auto_plan(dims, batch: int, has_context: bool):
     C = dims.residual_channels
     best = None
     for variant in (N.GEN_FOLD, N.GEN_PIPE):
-        t, group = _T_STEP_US.get((C, variant)), max_pipe_batch(dims, variant)
-        if t is None or group <= 0:
+        cap = max_pipe_batch(dims, variant)
+        if cap <= 0 or _T_STEP_US.get((C, variant)) is None:
             continue
-        cost = -(-batch // group) * t
+        k = -(-batch // cap)          # launches per step
+        group = -(-batch // k)        # balanced: the step time of a launch grows with its rounds
+        cost = k * _launch_step_us(dims, variant, group)
         if best is None or cost < best[0]:
             best = (cost, group, variant)
     if best is not None and best[0] < _T_SINGLE_US.get((C, bool(has_context)), 0.0):
@@ -282,11 +300,10 @@ def max_pipe_batch(dims, variant: int = N.GEN_PIPE) -> int:
 
 
 class GroupedGenerator:
-    """More sequences than one PIPE launch can hold (24 at config 2): groups of sequences
-    take turns on the pipelines, one launch per group per ``advance``.  Per sequence a PIPE
-    step costs 17.6 us against 78 us for the STREAM kernel, so three launches of 24 + 24 + 16
-    sequences (53 us per step of all 64) still beat one STREAM launch of 64 (78 us); from
-    five groups on they do not, and ``auto_plan`` picks one STREAM launch instead.
+    """More sequences than one pipelined launch can hold (FOLD: 128 at config 2, PIPE: 24;
+    C = 128: 4): groups of sequences take turns on the pipelines, one launch per group per
+    ``advance``; ``auto_plan`` picks this as long as the groups' step times add up to less than
+    one launch of a kernel that holds every sequence (STREAM: 78 us).
     Same interface as ``RingGenerator``; ``samples`` is one (B, n_total) tensor the groups
     write their row blocks of.  Each group draws from its own Philox key (seed + group)."""
 

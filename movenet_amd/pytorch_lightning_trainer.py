@@ -157,6 +157,38 @@ class Dance2Music(nn.Module):
         return optimizers
 
 
+class _DeferredRecord:
+    """One optimizer step's log record whose tensor values are still being computed.  The device
+    scalars are gathered into one tensor and copied to pinned host memory on the training stream,
+    with an event behind the copy; ``resolve()`` -- called a step later -- waits for THAT event
+    only.  (``float(tensor)`` is a synchronous copy on the current stream: it waits for everything
+    enqueued so far, i.e. it would serialise the host's enqueueing of step k + 1 with the GPU's
+    execution of it.)"""
+
+    def __init__(self, rec: dict):
+        self.rec = rec
+        self.keys = [k for k, v in rec.items() if torch.is_tensor(v)]
+        self.host, self.event = None, None
+        if self.keys:
+            dev = rec[self.keys[0]].device
+            vals = torch.stack([rec[k].detach().to(torch.float32).reshape(()) for k in self.keys])
+            if dev.type == "cuda":
+                self.host = torch.empty(len(self.keys), dtype=torch.float32).pin_memory()
+                self.host.copy_(vals, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(torch.cuda.current_stream(dev))
+            else:
+                self.host = vals
+
+    def resolve(self) -> dict:
+        if self.event is not None:
+            self.event.synchronize()
+        out = dict(self.rec)
+        if self.keys:
+            out.update(zip(self.keys, self.host.tolist()))
+        return out
+
+
 class Trainer:
     """The part of ``pytorch_lightning.Trainer.fit`` the reference relies on."""
 
@@ -205,11 +237,11 @@ class Trainer:
         pending = []  # records whose values are still device tensors
 
         def flush_records():
-            """Resolve the queued records (float() waits for the step that produced them -- which
-            is why a record is resolved only after the NEXT step has been enqueued), append them
-            to history, print / write them."""
+            """Resolve the queued records (waiting only for the step that produced them -- which
+            is why a record is resolved after the NEXT step has been enqueued), append them to
+            history, print / write them."""
             while pending:
-                rec = {k: (float(v) if torch.is_tensor(v) else v) for k, v in pending.pop(0).items()}
+                rec = pending.pop(0).resolve()
                 self.history.append(rec)
                 if rank == 0 and (rec["step"] + 1) % self.log_every == 0:
                     print(json.dumps(rec), flush=True)
@@ -260,7 +292,7 @@ class Trainer:
                         scheduler.step()
                     self.global_step += 1
                     flush_records()          # the PREVIOUS step's values: ready by now
-                    pending.append(rec)
+                    pending.append(_DeferredRecord(rec))
             flush_records()
             torch.cuda.synchronize(dev)
             epoch_s = time.perf_counter() - t0

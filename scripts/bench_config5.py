@@ -19,10 +19,13 @@ sd = {k: v.to(DEV) for k, v in make_state_dict(**cfg, seed=0).items() if not k.s
 rf, n_new = 6144, 22050
 flop_per_sample = 2 * (60 * (5 * 128 * 128 + 128 * 128) + 128 * 256 + 256 * 256)  # 11,993,088
 out = {}
+FP16_ONLY = "--fp16-only" in sys.argv
 for name, variant, batches in (("fp32 (gen_pipe_kernel<128>, 61 stages)", N.GEN_PIPE, (1, 4)),
                                ("fp16 operands / fp32 accumulate (gen_pipe_h16_kernel, 31 stages)", N.GEN_PIPE_F16, (1, 4, 8)),
                                ("fp32 generic kernel", N.GEN_GENERIC, (1,))):
     for B in batches:
+        if FP16_ONLY and (variant != N.GEN_PIPE_F16 or B != 1):
+            continue
         g = RingGenerator(**cfg, state_dict=sd, batch=B, n_total=rf + 2 * n_new + 1, device=DEV, variant=variant)
         g.prime_with_forward = True  # queue priming is outside the timed region either way
         g.prime(synthetic_indices(B, rf, 256, 1234).to(DEV))

@@ -18,9 +18,15 @@ pr.enable()
 line = bench.trainer_fit_line(dev)
 pr.disable()
 print(line, file=sys.stderr)
+ms = torch.cuda.memory_stats(dev)
+print({k: ms[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "reserved_bytes.all.peak",
+                          "allocated_bytes.all.peak", "allocation.all.allocated")}, file=sys.stderr)
 out = io.StringIO()
 pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(45)
 print(out.getvalue())
 out = io.StringIO()
-pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(25)
+st = pstats.Stats(pr, stream=out).sort_stats("tottime")
+st.print_stats(25)
+st.print_callers("method 'to' of")
+st.print_callers("pin_memory")
 print(out.getvalue())

@@ -44,14 +44,15 @@ def test_receptive_fields_and_output_size():
 def test_generate_sizes_and_variants():
     lib = N.lib()
     d2 = N.make_dims(10, 3, 256, 64, 64)
-    # 16 sequences x 9 pipeline stages fit the 256 CUs; 64 sequences do not
+    # FOLD: 16 eleven-stage pipelines fit the 256 CUs, each serving up to 8 sequences in turn (r3)
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_FOLD
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 17) == N.GEN_PIPE
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 64) == N.GEN_STREAM
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 17) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 128) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 129) == N.GEN_STREAM
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 64) == N.MVN_ERR_UNSUPPORTED
-    # one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 24) == N.GEN_PIPE
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 25) == N.GEN_STREAM
+    # PIPE: one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all
+    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 24) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 25) == N.MVN_ERR_UNSUPPORTED
     # BASELINE config 5 (60 layers, C=K=128): 61 stages span 2 XCDs -> 4 sequences
     d5 = N.make_dims(10, 6, 256, 128, 128)
     assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 4) == N.GEN_PIPE
@@ -64,10 +65,10 @@ def test_generate_sizes_and_variants():
     # C=K=64: the hand-off area is sized for the largest pipelined variant (FOLD: 11 stages of
     # 192 granules), the status word follows its granules
     assert lib.mvn_gen_status_offset(d2, 16) == 16 * (3069 * 64 + 11 * 384)
-    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 16) == N.GEN_FOLD
-    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 17) == N.MVN_ERR_UNSUPPORTED
-    assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 8) == N.GEN_PIPE_F16
-    assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 9) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 128) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 129) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 64) == N.GEN_PIPE_F16   # 8 pipelines x 8 rounds
+    assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 65) == N.MVN_ERR_UNSUPPORTED
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE_F16, 1) == N.MVN_ERR_UNSUPPORTED
     d1 = N.make_dims(2, 2, 64, 16, 16)
     assert lib.mvn_gen_variant(d1, N.GEN_AUTO, 2) == N.GEN_GENERIC

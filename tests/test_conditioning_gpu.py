@@ -133,7 +133,10 @@ def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypat
     (bwd_dctx_wgctx64_kernel).  8 clips of 6 frames (T = 6000: ragged against the 64-step tiles,
     and long enough that the scratch holds the fused form's slabs) against the generic kernels
     (MOVENET_HIP_NO_FUSED_BACKWARD=1, same process) and torch autograd on the oracle; the video
-    encoder's gradients are in the comparison, so the accumulated dctx is too."""
+    encoder's gradients are in the comparison, so the accumulated dctx is too.  The loss is a
+    weighted sum of squared LOGITS (as in test_fused_backward_kernels_match_two_kernel_forms_and_oracle):
+    the trainer's cross-entropy on probabilities has gradients of ~1e-8 that are sums of 48 000
+    terms of mixed sign, whose fp32 rounding alone is 1e-3 of their size on CPU and GPU alike."""
     import movenet_amd.wavenet as W
     frames, B = 6, 8
     T = 1000 * frames
@@ -144,7 +147,7 @@ def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypat
     dims = O.Dims(**cfg)
     x = one_hot(synthetic_indices(B, T, 256, 1234), 256)
     video = torch.from_numpy(np.random.default_rng(4321).random((B, frames, 64, 64, 1), dtype=np.float32))
-    target = x[:, :, dims.receptive_fields:].argmax(1)
+    w = torch.linspace(0.5, 1.5, 256).view(1, 256, 1)
 
     def grads(no_fused):
         if no_fused:
@@ -152,7 +155,8 @@ def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypat
         else:
             monkeypatch.delenv("MOVENET_HIP_NO_FUSED_BACKWARD", raising=False)
         m = _model(cfg, sd).train()
-        loss, _, _ = m(x.to(DEV), video.to(DEV), return_loss=True)
+        out = m(x.to(DEV), video.to(DEV), output_unnormalized=False)
+        loss = (out * w.to(DEV)).square().mean()
         loss.backward()
         return loss.item(), {k: (None if p.grad is None else p.grad.cpu()) for k, p in m.named_parameters()}
 
@@ -164,9 +168,9 @@ def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypat
             assert rel_err(fused[k], plain[k]) < 2e-5, k  # fp32 sums in another order
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ctx = O.upsample_video(params, video, expect_frames=T)
-    loss_o = F.cross_entropy(O.forward(params, dims, x, context=ctx), target)
+    loss_o = (O.forward(params, dims, x, context=ctx, output_unnormalized=False) * w).square().mean()
     loss_o.backward()
-    assert abs(loss_f - loss_o.item()) < 2e-6
+    assert abs(loss_f - loss_o.item()) < 2e-5 * abs(loss_o.item())
     for k, g in fused.items():
         if params[k].grad is None:
             assert g is None, k

@@ -196,7 +196,8 @@ def test_config2_full_size_properties():
 
 def test_config2_pipe_at_full_occupancy():
     """24 sequences = 3 nine-stage pipelines in each of the 8 XCDs (the most that are
-    co-resident): PIPE still equals STREAM, and one more sequence is refused for PIPE."""
+    co-resident): PIPE still equals STREAM, and one more sequence is refused for PIPE.  FOLD: 16
+    eleven-stage pipelines of up to 8 sequences each (r3)."""
     from movenet_amd.utils.weights import make_state_dict
     cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
     sd = make_state_dict(**cfg, seed=5, gain=2.0, head_gain=6.0)
@@ -210,11 +211,11 @@ def test_config2_pipe_at_full_occupancy():
         g.check_errors()
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
-    assert _gen(cfg, sd, 25, rf + 1).variant == N.GEN_STREAM  # AUTO falls back
-    assert _gen(cfg, sd, 24, rf + 1).variant == N.GEN_PIPE    # up to 24 sequences: the 9-stage pipelines
-    assert _gen(cfg, sd, 16, rf + 1, variant=N.GEN_FOLD).variant == N.GEN_FOLD  # 11-stage folded: <= 16
+    assert _gen(cfg, sd, 129, rf + 1).variant == N.GEN_STREAM  # AUTO falls back
+    assert _gen(cfg, sd, 24, rf + 1).variant == N.GEN_FOLD     # AUTO: FOLD wherever it holds the batch
+    assert _gen(cfg, sd, 128, rf + 1, variant=N.GEN_FOLD).variant == N.GEN_FOLD  # 16 pipelines x 8 rounds
     with pytest.raises(Exception):
-        _gen(cfg, sd, 17, rf + 1, variant=N.GEN_FOLD)
+        _gen(cfg, sd, 129, rf + 1, variant=N.GEN_FOLD)
     with pytest.raises(Exception):
         _gen(cfg, sd, 25, rf + 1, variant=N.GEN_PIPE)
 
@@ -244,6 +245,45 @@ def test_grouped_pipelines_beyond_one_launch():
     model.load_state_dict(sd, strict=False)
     out = model.to(DEV).generate(one_hot(pidx.cpu(), 256).to(DEV), n_samples=rf + n_new, temperature=0.0)
     assert torch.equal(out.argmax(1).to(torch.int32), ref.samples)
+
+
+@pytest.mark.parametrize("B", [40, 128])
+def test_fold_pipelines_serve_several_sequences_in_turn(B):
+    """r3: beyond 16 sequences a FOLD pipeline serves ceil(B / 16) sequences in turn within ONE
+    launch (gen_fold_kernel<true>: weights shared, one inbox per sequence and stage).  B = 40 leaves
+    the last round half empty, B = 128 is the full eight rounds.  Greedy indices bit-equal to the
+    STREAM kernel, chunked launches equal to one launch, teacher-forced logits within tolerance of
+    STREAM's, and sampled draws -- the Philox counter is (seed, step, SEQUENCE), whatever the
+    round -- equal to STREAM's on >= 99.9 % of the draws."""
+    from movenet_amd.utils.weights import make_state_dict
+    sd = make_state_dict(**CFG2, seed=6, gain=2.0, head_gain=6.0)
+    rf, n_new = 3072, 24
+    pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
+    ref = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_STREAM)
+    ref.prime(pidx)
+    ref.advance(n_new)
+    g = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_FOLD)
+    assert g.variant == N.GEN_FOLD
+    g.prime(pidx)
+    g.advance(n_new)
+    g.check_errors()
+    assert torch.equal(g.samples, ref.samples)
+    assert len(torch.unique(g.samples[:, rf:])) > 8
+    g2 = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_FOLD)
+    g2.prime(pidx)
+    g2.advance(10)
+    g2.advance(n_new - 10)
+    g2.check_errors()
+    assert torch.equal(g2.samples, ref.samples)
+    hist = synthetic_indices(B, rf + 40, 256, 4321).to(DEV)
+    picks, logits = {}, {}
+    for variant in (N.GEN_STREAM, N.GEN_FOLD):
+        gt = _gen(CFG2, sd, B, rf + 40, variant=variant, temperature=1.0, seed=77)
+        choices, lg = gt.teacher_forced(hist, logits_t0=rf)
+        gt.check_errors()
+        picks[variant], logits[variant] = choices[:, rf:].cpu().numpy(), lg.cpu().numpy()
+    assert rel_err(logits[N.GEN_FOLD], logits[N.GEN_STREAM]) < LOGIT_TOL
+    assert (picks[N.GEN_FOLD] == picks[N.GEN_STREAM]).mean() >= 0.999
 
 
 def test_bad_input_raises():
@@ -487,13 +527,13 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
 def test_auto_plan_cost_based():
     from movenet_amd.generation import auto_plan
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
-    assert auto_plan(d2, 16, False) == ("single", 0, N.GEN_FOLD)
-    assert auto_plan(d2, 20, False) == ("single", 0, N.GEN_PIPE)
-    assert auto_plan(d2, 32, False) == ("grouped", 16, N.GEN_FOLD)    # 2 x 15.0 us < 2 x 17.5 us
-    assert auto_plan(d2, 64, False) == ("grouped", 24, N.GEN_PIPE)    # 3 x 17.5 us < 4 x 15.0 us
-    assert auto_plan(d2, 96, False) == ("grouped", 24, N.GEN_PIPE)
-    assert auto_plan(d2, 97, False) == ("single", 0, N.GEN_STREAM)    # 5 x 17.5 us > 78 us
-    assert auto_plan(d2, 256, True) == ("grouped", 24, N.GEN_PIPE)    # no conditioned STREAM kernel
+    for n in (1, 16, 20, 32, 64, 128):                                 # one FOLD launch, 1 - 8 rounds
+        assert auto_plan(d2, n, False) == ("single", 0, N.GEN_FOLD)
+    assert auto_plan(d2, 129, False) == ("grouped", 65, N.GEN_FOLD)   # 2 x 5 rounds: 33 us < 78 us
+    assert auto_plan(d2, 256, False) == ("grouped", 128, N.GEN_FOLD)  # 2 x 26.4 us
+    assert auto_plan(d2, 300, False) == ("grouped", 100, N.GEN_FOLD)  # 3 x 23.1 us
+    assert auto_plan(d2, 400, False) == ("single", 0, N.GEN_STREAM)   # 4 x 23.1 us > 78 us
+    assert auto_plan(d2, 400, True) == ("grouped", 100, N.GEN_FOLD)   # no conditioned STREAM kernel
     assert auto_plan(d5, 4, False) == ("single", 0, N.GEN_PIPE)
     assert auto_plan(d5, 24, False) == ("grouped", 4, N.GEN_PIPE)
     assert auto_plan(d5, 25, False) == ("single", 0, N.GEN_GENERIC)
