@@ -64,30 +64,10 @@ def log(msg: str) -> None:
 
 
 def host_cores() -> int:
-    """Threads for the CPU baseline: the process's CPU share (affinity mask,
-    capped by the cgroup CPU quota), overridable with MOVENET_CPU_THREADS."""
-    if os.environ.get("MOVENET_CPU_THREADS"):
-        return max(1, int(os.environ["MOVENET_CPU_THREADS"]))
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
-                q = int(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
-                per = int(f.read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return min(n, 64)
+    """Threads for the CPU baseline: the process's CPU share (affinity mask, capped by the cgroup CPU
+    quota), overridable with MOVENET_CPU_THREADS."""
+    from movenet_amd.utils.host import cpu_share
+    return min(cpu_share(), 64)
 
 
 def cpu_model() -> str:
@@ -528,6 +508,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    from movenet_amd.utils.host import cap_torch_threads
+    cap_torch_threads()  # (torch sizes its OpenMP pool by the visible cores, not by the container's quota)
     # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and a
     # gloo process group, to exercise the N>1 control flow without a second GPU
     if os.environ.get("MOVENET_BENCH_SINGLE_DEVICE") == "1":
@@ -609,7 +591,6 @@ def main():
     # memory handed back fragmented is our reading, not verified)
     train, train3, fit = None, None, None
     if not args.no_train_leg:
-        from movenet_amd.ops import release_cached_buffers
         del gen
         torch.cuda.empty_cache()
         # both M2 workloads at every N: config 2 (audio only, BASELINE configs[1]) and config 3
@@ -627,7 +608,6 @@ def main():
                 train = line
             else:
                 train3 = line
-            release_cached_buffers()
             torch.cuda.empty_cache()
         if world == 1:
             try:
@@ -637,7 +617,6 @@ def main():
                 log(f"rank 0: Trainer.fit {fit['ms_per_step']:.2f} ms per step")
             except Exception as e:
                 fit = {"error": f"{type(e).__name__}: {e}"}
-            release_cached_buffers()
             torch.cuda.empty_cache()
 
     extras = None

@@ -105,15 +105,18 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
                               ACCUMULATION (BASELINE configs[4]; precedent: torch.autocast,
                               movenet/trainer.py:124): weights and every product's vector
                               operand rounded to fp16, v_dot2c_f32_f16 sums in fp32; two layers
-                              per stage, ceil(L/2)+1 stages (31 for 60 layers: one XCD).  Never
-                              chosen by MVN_GEN_AUTO: fp32 is the default precision.            */
+                              per stage, ceil(L/2)+1 stages (31 for 60 layers: one XCD): 8
+                              pipelines per launch, each serving up to 8 sequences in turn (64
+                              per launch).  Never chosen by MVN_GEN_AUTO: fp32 is the default.   */
 
 #define MVN_GEN_FOLD 5 /* C=K=64, Q=256: the PIPE structure with the residual 1x1 of layer j folded
                           into the filter/gate matrix of layer j+1 (products formed at pack
                           time): ONE dependent mat-vec + gate per layer instead of two; three
-                          layers per stage, ceil(L/3)+1 stages (11 for 30 layers), at most 16
-                          sequences co-resident.  15.0 us per step at config 2 against PIPE's
-                          17.5: what MVN_GEN_AUTO runs whenever it holds the batch.              */
+                          layers per stage, ceil(L/3)+1 stages (11 for 30 layers): 16 pipelines
+                          co-resident, each serving up to 8 sequences in turn within one launch
+                          (128 sequences).  Config 2: 14.7 us per step for 16 sequences (PIPE:
+                          17.5), 15.4 for 64, 21.1 for 128 (STREAM: 79): what MVN_GEN_AUTO runs
+                          whenever it holds the batch.                                          */
 
 /* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
  * variant or a negative error.  The packed weight layout depends on the variant:
@@ -311,6 +314,17 @@ int mvn_onehot_to_index(const float *onehot, int32_t *index, int batch, int clas
                         void *stream);
 int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, int batch,
                         int classes, int t_len, void *stream);
+
+/* Plumbing for the host wrappers (no reference counterpart): publish up to 64 device 32-bit words
+ * to the HOST without a copy engine or a stream synchronisation -- the one-hot validation's
+ * minimum index (the reference feeds one-hot tensors to a dense conv and never looks) and the
+ * trainer's per-step log scalars (loss, accuracy, gradient norm).  `host_words` points to n + 1
+ * words in pinned, device-visible host memory (hipHostMalloc / torch pin_memory()): one wave on
+ * `stream` stores words[0..n) to host_words[0..n), then `seq` to host_words[n] (system-scope
+ * release); the host polls host_words[n] == seq and so waits for exactly the kernels queued in
+ * front of this one -- a stream-synchronising read (tensor.item()) waits for everything the
+ * caller has enqueued since. */
+int mvn_publish_words(const uint32_t *words, int n, int32_t seq, uint32_t *host_words, void *stream);
 
 /* The trainer's loss and accuracy on the model output (row F3 of SURVEY.md section 8;
  * movenet/pytorch_lightning_trainer.py:64-66): cross_entropy applied to PROBABILITIES

@@ -146,6 +146,7 @@ SIGNATURES = {
                                       C.c_void_p]),
     "mvn_index_to_onehot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
+    "mvn_publish_words": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -304,6 +304,18 @@ __global__ __launch_bounds__(256) void ce_probs_cols_kernel(const float *__restr
 
 }  // namespace mvn
 
+namespace mvn {
+// one wave: device words to pinned host memory, the values first, then the sequence number the
+// host polls for (system scope: visible to the CPU without waiting for the end of the grid)
+__global__ void publish_words_kernel(const uint32_t *__restrict__ words, int n, int32_t seq, uint32_t *host_words) {
+  const int lane = threadIdx.x;
+  if (lane < n) __hip_atomic_store(host_words + lane, words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __builtin_amdgcn_s_barrier();
+  if (lane == 0) __hip_atomic_store(host_words + n, (uint32_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace mvn
+
 extern "C" {
 
 int mvn_ce_parts(int batch, int s_len) {
@@ -409,6 +421,15 @@ int mvn_onehot_to_index(const float *onehot, int32_t *index, int batch, int clas
   hipLaunchKernelGGL(mvn::onehot_to_index_kernel, grid, dim3(256), 0, (hipStream_t)stream, onehot,
                      index, classes, t_len);
   return mvn::check_hip(hipGetLastError(), "onehot_to_index");
+}
+
+int mvn_publish_words(const uint32_t *words, int n, int32_t seq, uint32_t *host_words, void *stream) {
+  if (!words || !host_words || n < 1 || n > 64) {
+    mvn::set_error("mvn_publish_words: NULL pointer or n outside 1..64");
+    return MVN_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(mvn::publish_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, n, seq, host_words);
+  return mvn::check_hip(hipGetLastError(), "mvn_publish_words");
 }
 
 int mvn_index_to_onehot(const int32_t *index, int index_stride, float *onehot, int batch,

@@ -92,20 +92,20 @@ class SyntheticLoader:
     def __len__(self) -> int:
         return math.ceil(len(self._order()) / self.batch_size)
 
-    def _clip(self, i: int) -> torch.Tensor:
+    def _clip(self, i: int) -> np.ndarray:
         rng = np.random.default_rng(self.seed * 1000003 + i)
-        return torch.from_numpy(rng.integers(0, self.Q, size=self.frames, dtype=np.int64))
+        return rng.integers(0, self.Q, size=self.frames, dtype=np.int64)
 
     def __iter__(self) -> Iterator[Batch]:
         order = self._order()
         crop_rng = random.Random(self.seed * 31 + self.epoch * 7 + self.rank)
         for s in range(0, len(order), self.batch_size):
             ids = order[s:s + self.batch_size]
-            idx = torch.stack([self._clip(i) for i in ids])
+            idx = np.stack([self._clip(i) for i in ids])
             if self.device is not None and self.device.type == "cuda":
                 audio = _one_hot_on_device(idx, self.Q, self.device)
             else:
-                audio = one_hot(idx, self.Q)
+                audio = one_hot(torch.from_numpy(idx), self.Q)
             if self.frac is not None:
                 n = math.ceil(audio.shape[-1] * self.frac)
                 start = crop_rng.randint(0, audio.shape[-1] - n)
@@ -115,67 +115,83 @@ class SyntheticLoader:
                 # U[0,1) frames, one 64x64 gray frame per 1000 samples
                 # (movenet/wavenet.py:27-31: 160 frames <-> 160000 samples)
                 vr = np.random.default_rng(self.seed * 7919 + 4321 + ids[0])
-                video = torch.from_numpy(
-                    vr.random((len(ids), self.frames // 1000, 64, 64, 1), dtype=np.float32))
+                frames = vr.random((len(ids), self.frames // 1000, 64, 64, 1), dtype=np.float32)
                 if self.device is not None and self.device.type == "cuda":
-                    video = _to_device_async(video, self.device)
+                    video = _to_device_async(frames, self.device)
+                else:
+                    video = torch.from_numpy(frames)
             yield Batch(audio, video, ["synthetic"] * len(ids),
                         [f"synthetic://{i}" for i in ids],
                         [dict(video_fps=0.0, audio_fps=float(self.frames) / 10.0)] * len(ids))
 
 
-_FEED_STREAMS: dict = {}
+class _PinnedRing:
+    """A few persistent pinned host buffers the loader stages its batches in, taken in turn; an
+    event behind each asynchronous copy says when its buffer may be overwritten (polled:
+    generation.wait_event).  Pinned + asynchronous: a copy from pageable memory makes the host wait
+    until everything queued on the stream -- the whole previous step -- has run."""
+
+    def __init__(self, slots: int = 4):
+        self.slots, self.next = [None] * slots, 0
+
+    def stage(self, src: np.ndarray) -> tuple:
+        """``src``: a numpy array.  It is copied into the slot with numpy (one thread): a torch CPU
+        op of this size opens an OpenMP region on every visible core, whose threads then spin for
+        their block time -- in a container with a CPU quota that alone can exhaust the quota of a
+        scheduler period and freeze the whole process for the rest of it (r3: 60-90 ms stalls at
+        arbitrary places of every second or third Trainer.fit step; none in loops without per-step
+        CPU tensor ops)."""
+        from .generation import wait_event
+        i, self.next = self.next, (self.next + 1) % len(self.slots)
+        slot = self.slots[i]
+        dtype = torch.from_numpy(np.empty(0, dtype=src.dtype)).dtype
+        if slot is None or tuple(slot[0].shape) != src.shape or slot[0].dtype != dtype:
+            slot = self.slots[i] = [torch.empty(src.shape, dtype=dtype).pin_memory(), None]
+        if slot[1] is not None:
+            wait_event(slot[1])
+        np.copyto(slot[0].numpy(), src)
+        return slot
+
+    @staticmethod
+    def to_device(slot, device: torch.device) -> torch.Tensor:
+        """Asynchronous copy on the CURRENT stream (pinned source: the host does not wait)."""
+        out = slot[0].to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
+        return out
 
 
-def _feed_stream(device: torch.device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _FEED_STREAMS.get(key)
-    if st is None:
-        st = _FEED_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
+_RINGS: dict = {}
 
 
-def _one_hot_on_device(idx: torch.Tensor, Q: int, device: torch.device) -> torch.Tensor:
-    """(B,T) int64 host indices -> (B,Q,T) fp32 one-hot on ``device`` through the C ABI.
+def _ring(kind: str, device: torch.device) -> _PinnedRing:
+    key = (kind, device.index)
+    if key not in _RINGS:
+        _RINGS[key] = _PinnedRing()
+    return _RINGS[key]
 
-    The indices (4 bytes per sample) cross PCIe from pinned memory on a FEED stream of their own;
-    the consumer's stream waits for that copy's event and expands them itself (mvn_index_to_onehot:
-    ~70 us for 16 x 256 x 16000).  A copy from pageable memory on the training stream would make the
-    host wait until everything queued there -- the whole previous step -- has run, i.e. the loader
-    would serialise host and GPU.  The large one-hot tensor is allocated on the TRAINING stream: a
-    block handed from one stream's pool to another is not reusable until the other stream's work
-    on it has been seen to finish, and the allocator then asks the driver for a new 262 MB block
-    every step."""
+
+def _one_hot_on_device(idx: np.ndarray, Q: int, device: torch.device) -> torch.Tensor:
+    """(B,T) integer host indices (numpy) -> (B,Q,T) fp32 one-hot on ``device`` through the C ABI (row F2).
+
+    The indices (4 bytes per sample) cross PCIe from a persistent pinned staging buffer as an
+    asynchronous copy on the training stream, which then expands them itself
+    (mvn_index_to_onehot: ~70 us for 16 x 256 x 16000).  A copy from pageable memory would make
+    the host wait until everything queued on that stream -- the whole previous step -- has run."""
     from . import _native as N
     B, T = idx.shape
-    main = torch.cuda.current_stream(device)
-    feed = _feed_stream(device)
-    pinned = idx.to(torch.int32).pin_memory()
     with torch.cuda.device(device):
-        with torch.cuda.stream(feed):
-            d_idx = pinned.to(device, non_blocking=True)
-            ready = torch.cuda.Event()
-            ready.record(feed)
-        main.wait_event(ready)
-        d_idx.record_stream(main)
+        d_idx = _PinnedRing.to_device(_ring("idx", device).stage(np.ascontiguousarray(idx, dtype=np.int32)), device)
         out = torch.empty(B, Q, T, dtype=torch.float32, device=device)
         N.check(N.lib().mvn_index_to_onehot(d_idx.data_ptr(), d_idx.stride(0), out.data_ptr(), B, Q, T,
-                                            main.cuda_stream), "mvn_index_to_onehot")
+                                            torch.cuda.current_stream(device).cuda_stream), "mvn_index_to_onehot")
     return out
 
 
-def _to_device_async(x: torch.Tensor, device: torch.device) -> torch.Tensor:
-    """Host tensor -> device through pinned memory on the feed stream (see _one_hot_on_device)."""
-    main = torch.cuda.current_stream(device)
-    feed = _feed_stream(device)
-    pinned = x.pin_memory()
-    with torch.cuda.device(device), torch.cuda.stream(feed):
-        out = pinned.to(device, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record(feed)
-    main.wait_event(ready)
-    out.record_stream(main)
-    return out
+def _to_device_async(x: np.ndarray, device: torch.device) -> torch.Tensor:
+    """Host array -> device through the pinned staging ring (see _one_hot_on_device)."""
+    with torch.cuda.device(device):
+        return _PinnedRing.to_device(_ring("video", device).stage(np.ascontiguousarray(x)), device)
 
 
 def get_dataloader(filepath, input_channels: int, batch_size: int = 64, train: bool = True,

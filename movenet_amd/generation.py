@@ -19,6 +19,64 @@ class PipeHandoffTimeout(RuntimeError):
     that call are NOT valid."""
 
 
+def wait_event(event, spin_s: float = 5.0) -> None:
+    """Host wait for a recorded torch.cuda.Event by polling it (a core polling for the few
+    milliseconds of a step costs nothing that matters: one process drives one GPU)."""
+    import time
+    t0 = time.perf_counter()
+    while not event.query():
+        if time.perf_counter() - t0 > spin_s:
+            event.synchronize()
+            return
+
+
+class HostWords:
+    """Device scalars read by the host WITHOUT a stream synchronisation, a second stream or a copy
+    engine (``mvn_publish_words``): a ring of slots in pinned, device-visible host memory per
+    device; a one-wave kernel queued on the producing stream writes up to 64 32-bit words and then
+    a sequence number the host polls for.  ``publish`` returns a token, ``read`` spins on it.
+
+    ``tensor.item()`` waits for everything enqueued on the stream so far -- read in the middle of a
+    training step it would serialise the host's enqueueing with the GPU's execution.  Here the host
+    waits exactly for the kernels in front of the publish kernel (the one-hot check of
+    WaveNet.forward, published BEFORE the forward is enqueued; the trainer's log scalars, read one
+    step late)."""
+    RING, MAXW = 16, 64
+    _rings: dict = {}
+
+    @classmethod
+    def publish(cls, words: torch.Tensor):
+        """``words``: 1-D device tensor of <= 64 int32 / float32 values (already computed or being
+        computed on the current stream).  Returns the token ``read`` takes."""
+        dev = words.device
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        ring = cls._rings.get(key)
+        if ring is None:
+            ring = cls._rings[key] = [torch.zeros(cls.RING, cls.MAXW + 1, dtype=torch.int32).pin_memory(), 0]
+        ring[1] += 1
+        seq = (ring[1] & 0x3FFFFFFF) or 1
+        slot = ring[0][ring[1] % cls.RING]
+        n = int(words.numel())
+        if not 1 <= n <= cls.MAXW or words.dtype not in (torch.int32, torch.float32) or not words.is_contiguous():
+            raise ValueError("HostWords.publish: 1..64 contiguous int32 / float32 values")
+        with torch.cuda.device(dev):
+            N.check(N.lib().mvn_publish_words(words.data_ptr(), n, seq, slot.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "mvn_publish_words")
+        return slot, n, seq, words  # (words kept alive until read)
+
+    @staticmethod
+    def read(token, timeout_s: float = 30.0):
+        """The published values as a list of Python ints / floats (by the dtype of ``words``)."""
+        import time
+        slot, n, seq, words = token
+        t0 = time.perf_counter()
+        while int(slot[n]) != seq:
+            if time.perf_counter() - t0 > timeout_s:  # (never seen: the blocking form as a last resort)
+                return words.tolist()
+        vals = slot[:n]
+        return vals.tolist() if words.dtype == torch.int32 else vals.view(torch.float32).tolist()
+
+
 def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -231,11 +289,12 @@ class RingGenerator:
 
 # measured microseconds per generated sample-step of ONE launch; keys:
 # (C, variant).  PIPE: any number of co-resident sequences up to the variant's limit.  FOLD: its
-# 16 pipelines (config 2) serve ceil(n / 16) sequences each in turn (r3): 14.8 us for one round,
-# ~15.5 up to five, then the stages' service time per turn (~3.3 us) bounds the step.
+# 16 pipelines (config 2) serve ceil(n / 16) sequences each in turn (r3): 14.7 us for one round,
+# ~15.4 up to five, then the stages' service time per turn (~2.64 us) bounds the step
+# (96: 15.9 us, 112: 18.5, 128: 21.1).
 _T_STEP_US = {(64, N.GEN_FOLD): 15.0, (64, N.GEN_PIPE): 17.5, (128, N.GEN_PIPE): 79.0}
 _FOLD_ROUNDS = 8          # fold::GMAX of csrc/generate_fold.hip
-_FOLD_TURN_US = 3.3
+_FOLD_TURN_US = 2.64
 # ... and of the best kernel that takes EVERY sequence in one launch; keys: (C, conditioned):
 # STREAM at C=64 without conditioning, GENERIC otherwise
 _T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128, True): 490.0}
@@ -260,7 +319,7 @@ def auto_plan(dims, batch: int, has_context: bool):
     ``group`` sequences taking turns on the pipelines of a pipelined variant.
 
     Chosen on measured per-step cost.  C=K=64: ONE FOLD launch holds up to 128 sequences (16
-    pipelines x 8 rounds: 14.8 us for 16, 15.5 for 64, 26 for 128); beyond that balanced groups
+    pipelines x 8 rounds: 14.7 us for 16, 15.4 for 64, 21.1 for 128); beyond that balanced groups
     of FOLD launches take turns as long as they beat the one-launch kernels (STREAM 78 us /
     conditioned GENERIC ~0.3 ms for any number).  C=K=128: PIPE 79 us for up to 4, groups of 4
     up to 24, GENERIC 490 us beyond."""

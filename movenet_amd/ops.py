@@ -66,71 +66,6 @@ class VideoGradSlot:
         return views
 
 
-class _BufferPool:
-    """The large device buffers of the full-sequence path, kept from step to step.
-
-    A config-2 training step needs 6 GB of saved activations and 0.8 GB of backward scratch,
-    every step the same shapes.  Taken from torch's caching allocator each step they compete
-    with whatever else comes and goes in between (the loader's 262 MB one-hot batches, the
-    212 MB probability tensor): a freed 2 GB block is split for a 262 MB request, the next step's
-    2 GB request then finds no block and goes to the driver -- 70-90 ms, device-synchronising
-    (r3: Trainer.fit steps of 13 ms interleaved with steps of 80-95 ms).  Here a set of buffers
-    is handed out per (device, stream, shapes) key and comes back when its holder dies; at most
-    ``MAX_FREE`` idle sets per key and ``MAX_KEYS`` keys are kept (oldest key dropped first).
-    MOVENET_HIP_NO_BUFFER_POOL=1 allocates per call as before."""
-    MAX_FREE, MAX_KEYS = 2, 6
-
-    def __init__(self):
-        self.free = {}  # key -> [dict name -> tensor]; insertion order = age
-
-    @staticmethod
-    def enabled() -> bool:
-        import os
-        return os.environ.get("MOVENET_HIP_NO_BUFFER_POOL") != "1"
-
-    def acquire(self, key, make):
-        sets = self.free.get(key)
-        if sets:
-            return sets.pop()
-        return make()
-
-    def release(self, key, tensors) -> None:
-        if not self.enabled():
-            return
-        sets = self.free.pop(key, [])  # (re-inserted below: most recently used key last)
-        if len(sets) < self.MAX_FREE:
-            sets.append(tensors)
-        self.free[key] = sets
-        while len(self.free) > self.MAX_KEYS:
-            self.free.pop(next(iter(self.free)))
-
-    def clear(self) -> None:
-        self.free.clear()
-
-
-_POOL = _BufferPool()
-
-
-def release_cached_buffers() -> None:
-    """Drop the idle buffer sets (then ``torch.cuda.empty_cache()`` returns them to the driver)."""
-    _POOL.clear()
-
-
-class _Pooled:
-    """Holder of one buffer set; the set goes back to the pool when the holder dies (for the
-    forward's buffers: with the autograd node, i.e. after backward -- a retained graph keeps it)."""
-
-    def __init__(self, key, make):
-        self._key = (key, ) if not _POOL.enabled() else key
-        self.t = _POOL.acquire(key, make) if _POOL.enabled() else make()
-
-    def __del__(self):
-        try:
-            _POOL.release(self._key, self.t)
-        except Exception:  # interpreter shutdown
-            pass
-
-
 class ForwardBuffers:
     """Device buffers of one forward pass (sizes: include/movenet_hip.h)."""
 
@@ -142,20 +77,12 @@ class ForwardBuffers:
         S = N.check(lib.mvn_output_size(dims, t_len), "mvn_output_size")
         self.S, self.Tp, self.Sp = S, lib.mvn_padded_len(t_len), lib.mvn_padded_len(S + 31)
         f32 = dict(dtype=torch.float32, device=device)
-        Tp, Sp = self.Tp, self.Sp
-
-        def make():
-            return dict(acts=torch.empty(((L + 1) if save else 2, batch, C, Tp), **f32),
-                        th=torch.empty((L, batch, C, Tp), **f32) if save else None,
-                        sg=torch.empty((L, batch, C, Tp), **f32) if save else None,
-                        z=torch.empty((batch, C, Tp), **f32), skip=torch.empty((batch, K, Sp), **f32),
-                        a1=torch.empty((batch, Q, Sp), **f32))
-
-        dev = torch.device(device)
-        self._hold = _Pooled(("fwd", dev.index, torch.cuda.current_stream(dev).cuda_stream, L, C, K, Q, batch, Tp, Sp,
-                              bool(save)), make)
-        t = self._hold.t
-        self.acts, self.th, self.sg, self.z, self.skip, self.a1 = t["acts"], t["th"], t["sg"], t["z"], t["skip"], t["a1"]
+        self.acts = torch.empty(((L + 1) if save else 2, batch, C, self.Tp), **f32)
+        self.th = torch.empty((L, batch, C, self.Tp), **f32) if save else None
+        self.sg = torch.empty((L, batch, C, self.Tp), **f32) if save else None
+        self.z = torch.empty((batch, C, self.Tp), **f32)
+        self.skip = torch.empty((batch, K, self.Sp), **f32)
+        self.a1 = torch.empty((batch, Q, self.Sp), **f32)
         self.ctx = ctx
         self.struct = N.FwdBuffers(
             self.acts.data_ptr(), self.th.data_ptr() if save else None,
@@ -263,20 +190,13 @@ def _run_backward(ctx_, params, out, dout, fill_dlogit):
                          gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b,
                          gp.ctx_filter_w, gp.ctx_filter_b, gp.ctx_gate_w, gp.ctx_gate_b)
         f32 = dict(dtype=torch.float32, device=dev)
-        has_ctx = bool(ctx_.has_context)
-
-        def make():
-            return dict(dx_a=torch.empty((B, C, buf.Tp), **f32), dx_b=torch.empty((B, C, buf.Tp), **f32),
-                        dfg=torch.empty((B, 2 * C, buf.Tp), **f32), dskip=torch.empty((B, K, buf.Sp), **f32),
-                        da1=torch.empty((B, Q, buf.Sp), **f32), dlogit=torch.empty((B, Q, buf.Sp), **f32))
-
-        # (scratch of this call only: back in the pool when `hold` dies at return -- the kernels
-        # enqueued here and the next call's run on the same stream, in order)
-        hold = _Pooled(("bwd", dev.index, torch.cuda.current_stream(dev).cuda_stream, C, K, Q, B, buf.Tp, buf.Sp), make)
-        dx_a, dx_b, dfg = hold.t["dx_a"], hold.t["dx_b"], hold.t["dfg"]
-        dskip, da1, dlogit = hold.t["dskip"], hold.t["da1"], hold.t["dlogit"]
-        # (the context gradient is handed to autograd: never pooled)
-        dctx = torch.empty((B, C, buf.Tp), **f32) if has_ctx else None
+        dx_a = torch.empty((B, C, buf.Tp), **f32)
+        dx_b = torch.empty((B, C, buf.Tp), **f32)
+        dfg = torch.empty((B, 2 * C, buf.Tp), **f32)
+        dskip = torch.empty((B, K, buf.Sp), **f32)
+        da1 = torch.empty((B, Q, buf.Sp), **f32)
+        dlogit = torch.empty((B, Q, buf.Sp), **f32)
+        dctx = torch.empty((B, C, buf.Tp), **f32) if ctx_.has_context else None
         bw = N.BwdBuffers(dx_a.data_ptr(), dx_b.data_ptr(), dfg.data_ptr(), dskip.data_ptr(),
                           da1.data_ptr(), dlogit.data_ptr(),
                           None if dctx is None else dctx.data_ptr())

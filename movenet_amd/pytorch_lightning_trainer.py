@@ -29,6 +29,8 @@ import torch.nn as nn
 from .config import TrainingConfig, arg_parser, config_from_args
 from .dataset import get_dataloader
 from .optim import FlatAdamW, order_like_backward
+from .generation import HostWords
+from .utils.host import cap_torch_threads
 from .parallel import FlatGradSync, contiguous_grad_span, init_distributed
 from .wavenet import WaveNet
 
@@ -159,33 +161,27 @@ class Dance2Music(nn.Module):
 
 class _DeferredRecord:
     """One optimizer step's log record whose tensor values are still being computed.  The device
-    scalars are gathered into one tensor and copied to pinned host memory on the training stream,
-    with an event behind the copy; ``resolve()`` -- called a step later -- waits for THAT event
-    only.  (``float(tensor)`` is a synchronous copy on the current stream: it waits for everything
+    scalars are gathered into one tensor and published to pinned host memory by a kernel queued
+    behind them (generation.HostWords); ``resolve()`` -- called a step later -- polls for it.
+    (``float(tensor)`` is a synchronous copy on the current stream: it waits for everything
     enqueued so far, i.e. it would serialise the host's enqueueing of step k + 1 with the GPU's
     execution of it.)"""
 
     def __init__(self, rec: dict):
         self.rec = rec
         self.keys = [k for k, v in rec.items() if torch.is_tensor(v)]
-        self.host, self.event = None, None
+        self.token, self.host = None, None
         if self.keys:
-            dev = rec[self.keys[0]].device
             vals = torch.stack([rec[k].detach().to(torch.float32).reshape(()) for k in self.keys])
-            if dev.type == "cuda":
-                self.host = torch.empty(len(self.keys), dtype=torch.float32).pin_memory()
-                self.host.copy_(vals, non_blocking=True)
-                self.event = torch.cuda.Event()
-                self.event.record(torch.cuda.current_stream(dev))
+            if vals.is_cuda:
+                self.token = HostWords.publish(vals)
             else:
-                self.host = vals
+                self.host = vals.tolist()
 
     def resolve(self) -> dict:
-        if self.event is not None:
-            self.event.synchronize()
         out = dict(self.rec)
         if self.keys:
-            out.update(zip(self.keys, self.host.tolist()))
+            out.update(zip(self.keys, HostWords.read(self.token) if self.token is not None else self.host))
         return out
 
 
@@ -221,6 +217,7 @@ class Trainer:
                                                    model.config.dist_port)
         model.rank, model.world_size = rank, world
         self.rank = rank
+        cap_torch_threads()  # the container's CPU share, not the visible cores (utils/host.py)
         dev = torch.device(self.device) if self.device else torch.device("cuda", local_rank)
         if dev.type != "cuda":
             raise RuntimeError("movenet_amd trains on MI355X devices only (no CPU path)")

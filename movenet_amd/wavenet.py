@@ -25,8 +25,8 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
-from .generation import (GroupedGenerator, PipeHandoffTimeout, RingGenerator, _require_gpu, _stream_ptr,
-                         auto_plan, max_pipe_batch)
+from .generation import (GroupedGenerator, HostWords, PipeHandoffTimeout, RingGenerator, _require_gpu,
+                         _stream_ptr, auto_plan, max_pipe_batch)
 
 # module constants other movenet files import (movenet/wavenet.py:27-31)
 MAX_AUDIO_FRAMES = 160000
@@ -40,19 +40,6 @@ def upsample_kernel_size_solver(in_size, out_size, stride=1, padding=0, output_p
     (the ConvTranspose1d length formula); same contract as movenet/wavenet.py:34-47."""
     span = out_size - 1 - output_padding - (in_size - 1) * stride + 2 * padding
     return (int(span / dilation + 1),)
-
-
-# side streams for reading the one-hot check, one per device.  Kept OUTSIDE the module: a
-# torch.Stream in a module's __dict__ makes copy.deepcopy(model) / torch.save(model) fail.
-_CHECK_STREAMS: dict = {}
-
-
-def _check_stream(dev: torch.device):
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    side = _CHECK_STREAMS.get(key)
-    if side is None:
-        side = _CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return side
 
 
 class _Named(nn.Module):
@@ -157,10 +144,10 @@ class WaveNet(nn.Module):
 
     # ---- helpers --------------------------------------------------------
     def _indices_async(self, audio: torch.Tensor):
-        """(B,Q,T) one-hot -> ((B,T) int32 indices on device, 0-dim tensor = their minimum).
-        Nothing synchronises here: the minimum is -1 where a column is not exactly one-hot,
-        and the caller reads it (``.item()``) only AFTER it has enqueued the work that
-        assumes one-hot input, so the host never waits on an idle GPU."""
+        """(B,Q,T) one-hot -> ((B,T) int32 indices on device, check token).  Nothing synchronises
+        here: the indices' minimum is -1 where a column is not exactly one-hot, and the caller
+        reads it (``_all_one_hot``) only AFTER it has enqueued the work that assumes one-hot
+        input, so the host never waits on an idle GPU."""
         _require_gpu(audio, "audio")
         if audio.dim() != 3 or audio.size(1) != self.input_channels:
             raise ValueError(f"audio must be (batch, {self.input_channels}, frames), "
@@ -172,20 +159,16 @@ class WaveNet(nn.Module):
             N.check(N.lib().mvn_onehot_to_index(x.data_ptr(), idx.data_ptr(), B, Q, T,
                                                 _stream_ptr(x.device)), "mvn_onehot_to_index")
         low = idx.min() if B * T else torch.zeros((), dtype=torch.int32, device=x.device)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(x.device))
-        return idx, (low, ready)
+        # the minimum goes to pinned host memory from a one-wave kernel queued right behind the
+        # kernels that produce it -- ahead of whatever the caller enqueues next (generation.HostWords;
+        # nothing of it lives in the module: copy.deepcopy(model) / torch.save(model) keep working)
+        return idx, HostWords.publish(low.reshape(1))
 
     def _all_one_hot(self, check) -> bool:
-        """Read the minimum of ``_indices_async`` on a side stream that waits ONLY for the
-        kernels that produced it -- not for whatever the caller has enqueued since."""
-        low, ready = check
-        dev = low.device
-        side = _check_stream(dev)
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            low.record_stream(side)
-            return int(low.item()) >= 0
+        """The result of ``_indices_async``'s check: polls the pinned word its publish kernel
+        writes (no HIP call, no stream synchronisation: the host waits ONLY for the kernels that
+        produced the minimum, not for whatever the caller has enqueued since)."""
+        return HostWords.read(check)[0] >= 0
 
     def _indices_of(self, audio: torch.Tensor, strict: bool = True):
         """(B,Q,T) one-hot -> (B,T) int32 on device (mvn_onehot_to_index).  A column that

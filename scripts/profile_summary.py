@@ -21,9 +21,19 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+# every pass of scripts/profile_round.sh must have exited 0 (r2: passes that ended in SIGSEGV at
+# process exit fed this summary unnoticed)
+passes = os.path.join(src, "passes.txt")
+if not os.path.exists(passes):
+    sys.exit(f"{passes} is missing: run scripts/profile_round.sh {tag} first")
+lines = open(passes).read().strip().splitlines()
+bad = [ln for ln in lines if " rc=" in ln and not ln.endswith("rc=0")]
+if bad or not lines or lines[-1] != "all passes ok":
+    sys.exit(f"profile round {tag} is incomplete or has failed passes: {bad or lines[-1:]}")
+shutil_passes = os.path.join(dst, f"{tag}_passes.txt")
 
 
 def one(pattern):
@@ -34,8 +44,10 @@ def one(pattern):
 for name, pat in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json")):
     if one(pat):
         shutil.copy(one(pat), os.path.join(dst, f"{tag}_{name}"))
+shutil.copy(passes, shutil_passes)
 for name, pat in (("bench_kernel_stats.csv", "bench_trace/**/*kernel_stats.csv"),
-                  ("train_kernel_stats.csv", "tr_trace/**/*kernel_stats.csv")):
+                  ("train_kernel_stats.csv", "tr2_trace/**/*kernel_stats.csv"),
+                  ("train_config3_kernel_stats.csv", "tr3_trace/**/*kernel_stats.csv")):
     if one(pat):
         shutil.copy(one(pat), os.path.join(dst, f"{tag}_{name}"))
 
@@ -68,23 +80,24 @@ def counters(pattern):
     return out
 
 
-summary = {"note": __doc__.split("MFMA utilisation")[0].strip().splitlines()[0], "kernels": {}}
-mf, fe, wr = counters("tr_mfma"), counters("tr_fetch"), counters("tr_write")
-for k in sorted(mf, key=lambda k: -mf[k].get("duration_ns", 0) * mf[k].get("calls", 0)):
-    m = mf[k]
-    d = m.get("duration_ns")
-    if not d or m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) == 0:
-        continue
-    clock_ghz = m.get("GRBM_GUI_ACTIVE", 0) / 8 / d
-    e = {"calls": m["calls"], "duration_us_under_pmc": d / 1e3, "clock_GHz": round(clock_ghz, 3),
-         "SQ_VALU_MFMA_BUSY_CYCLES": m["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_BUSY_CYCLES": m.get("SQ_BUSY_CYCLES"),
-         "mfma_util": round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * d * clock_ghz), 4) if clock_ghz else None}
-    f, w = fe.get(k, {}), wr.get(k, {})
-    if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
-        df, dw = f.get("duration_ns", d), w.get("duration_ns", d)
-        e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = f["FETCH_SIZE"], w["WRITE_SIZE"]
-        e["hbm_GBps_fetch_x2_corrected"] = round((2 * f["FETCH_SIZE"] * 1024 / df + w["WRITE_SIZE"] * 1024 / dw), 1)
-    summary["kernels"][k] = e
+summary = {"note": __doc__.split("MFMA utilisation")[0].strip().splitlines()[0], "kernels": {}, "kernels_config3": {}}
+for section, pre in (("kernels", "tr2"), ("kernels_config3", "tr3")):
+    mf, fe, wr = counters(pre + "_mfma"), counters(pre + "_fetch"), counters(pre + "_write")
+    for k in sorted(mf, key=lambda k: -mf[k].get("duration_ns", 0) * mf[k].get("calls", 0)):
+        m = mf[k]
+        d = m.get("duration_ns")
+        if not d or m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) == 0:
+            continue
+        clock_ghz = m.get("GRBM_GUI_ACTIVE", 0) / 8 / d
+        e = {"calls": m["calls"], "duration_us_under_pmc": d / 1e3, "clock_GHz": round(clock_ghz, 3),
+             "SQ_VALU_MFMA_BUSY_CYCLES": m["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_BUSY_CYCLES": m.get("SQ_BUSY_CYCLES"),
+             "mfma_util": round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * d * clock_ghz), 4) if clock_ghz else None}
+        f, w = fe.get(k, {}), wr.get(k, {})
+        if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+            df, dw = f.get("duration_ns", d), w.get("duration_ns", d)
+            e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = f["FETCH_SIZE"], w["WRITE_SIZE"]
+            e["hbm_GBps_fetch_x2_corrected"] = round((2 * f["FETCH_SIZE"] * 1024 / df + w["WRITE_SIZE"] * 1024 / dw), 1)
+        summary[section][k] = e
 gf, gw = counters("gen_fetch"), counters("gen_write")
 for k in gf:
     if "gen_" in k and "kernel" in k and k in gw:

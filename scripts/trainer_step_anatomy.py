@@ -16,6 +16,9 @@ from movenet_amd.pytorch_lightning_trainer import Dance2Music  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
+if "--no-thread-cap" not in sys.argv:  # (as Trainer.fit does; without it: the r3 stall hunt's setting)
+    from movenet_amd.utils.host import cap_torch_threads
+    print("torch intra-op threads:", cap_torch_threads())
 
 # ---- fine timers inside training_step: wrap the callables it goes through
 import movenet_amd.ops as ops_mod  # noqa: E402

@@ -115,24 +115,29 @@ def test_fp16_free_run_and_model_api():
 
 def test_config5_full_length_one_second_of_audio():
     """BASELINE configs[4] at its STATED length: 22 050 samples (1 s of 22.05 kHz audio) generated
-    greedily by the fp16-operand kernel from an RF = 6144 prompt, batch 1, in ONE launch.
+    by the fp16-operand kernel from an RF = 6144 prompt, batch 1, in ONE launch -- sampled at the
+    reference's default temperature 1.0 (a greedy run of random weights settles into a cycle of
+    three classes within a few hundred steps; sampling keeps the second of audio varied).
       * three chunked launches (7000 + 7000 + 8050 steps) produce the same 22 050 samples;
-      * teacher-forced over its own history the kernel reproduces its own choices;
+      * teacher-forced over its own history the kernel reproduces >= 99.9 % of its own draws (the
+        free run's queues were primed by the fp16 FORWARD over the prompt, the teacher-forced pass
+        steps through it: same rounding points, another summation order -- a draw can change only
+        where the uniform falls within that rounding of a CDF edge);
       * against the fp32 ring oracle (C restatement, pinned by G2/G3) fed that same history, on a
         SAMPLED subset of the steps (every 89th: 248 of them, spread over the whole second):
-        logits within FP16_TOL of the fp32 logit range, and the same class wherever the fp32
+        logits within FP16_TOL of the fp32 logit range, and the same arg-max wherever the fp32
         top-2 margin exceeds twice the tolerance."""
     sd = make_state_dict(**CFG5, seed=2, gain=1.5, head_gain=6.0)
     dims = O.Dims(**CFG5)
     rf, n_new, B = dims.receptive_fields, 22050, 1
     pidx = synthetic_indices(B, rf, 256, 5)
-    g = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16)
+    g = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16, temperature=1.0, seed=7)
     g.prime(pidx.to(DEV))
     g.advance(n_new)               # one launch, 22 050 steps
     g.check_errors()
     run = g.samples.clone()
-    assert len(torch.unique(run[:, rf:])) > 8
-    g2 = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16)
+    assert len(torch.unique(run[:, rf:])) > 32
+    g2 = _gen(CFG5, sd, B, rf + n_new, N.GEN_PIPE_F16, temperature=1.0, seed=7)
     g2.prime(pidx.to(DEV))
     for n in (7000, 7000, 8050):
         g2.advance(n)
@@ -140,9 +145,9 @@ def test_config5_full_length_one_second_of_audio():
     assert torch.equal(g2.samples, run)
     choices, logits = g.teacher_forced(run, logits_t0=rf)
     g.check_errors()
-    assert torch.equal(choices[:, rf:], run[:, rf:])
+    assert (choices[:, rf:] == run[:, rf:]).float().mean().item() >= 0.999
     hist = run.cpu().numpy()
-    c32, l32 = ring_c.generate_ring_c(sd, dims, hist[:, :rf], rf + n_new, forced_idx=hist, threads=1)
+    _, l32 = ring_c.generate_ring_c(sd, dims, hist[:, :rf], rf + n_new, forced_idx=hist, threads=1)
     sub = np.arange(0, n_new, 89)
     lg16, lg32 = logits.cpu().numpy()[:, sub], l32[:, sub]
     scale = np.abs(l32).max()
@@ -152,7 +157,7 @@ def test_config5_full_length_one_second_of_audio():
     top2 = np.sort(lg32, axis=2)[:, :, -2:]
     clear = (top2[:, :, 1] - top2[:, :, 0]) > 2 * FP16_TOL * scale
     assert clear.mean() > 0.5
-    assert np.array_equal(hist[:, rf:][:, sub][clear], c32[:, rf:][:, sub][clear])
+    assert np.array_equal(lg16.argmax(2)[clear], lg32.argmax(2)[clear])
 
 
 def test_fp16_pipelines_serve_several_sequences_in_turn():

@@ -529,11 +529,11 @@ def test_auto_plan_cost_based():
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
     for n in (1, 16, 20, 32, 64, 128):                                 # one FOLD launch, 1 - 8 rounds
         assert auto_plan(d2, n, False) == ("single", 0, N.GEN_FOLD)
-    assert auto_plan(d2, 129, False) == ("grouped", 65, N.GEN_FOLD)   # 2 x 5 rounds: 33 us < 78 us
-    assert auto_plan(d2, 256, False) == ("grouped", 128, N.GEN_FOLD)  # 2 x 26.4 us
-    assert auto_plan(d2, 300, False) == ("grouped", 100, N.GEN_FOLD)  # 3 x 23.1 us
-    assert auto_plan(d2, 400, False) == ("single", 0, N.GEN_STREAM)   # 4 x 23.1 us > 78 us
-    assert auto_plan(d2, 400, True) == ("grouped", 100, N.GEN_FOLD)   # no conditioned STREAM kernel
+    assert auto_plan(d2, 129, False) == ("grouped", 65, N.GEN_FOLD)   # 2 x 5 rounds: 31 us < 78 us
+    assert auto_plan(d2, 256, False) == ("grouped", 128, N.GEN_FOLD)  # 2 x 21.1 us
+    assert auto_plan(d2, 400, False) == ("grouped", 100, N.GEN_FOLD)  # 4 x 18.5 us
+    assert auto_plan(d2, 500, False) == ("single", 0, N.GEN_STREAM)   # 4 x 21.1 us > 78 us
+    assert auto_plan(d2, 500, True) == ("grouped", 125, N.GEN_FOLD)   # no conditioned STREAM kernel
     assert auto_plan(d5, 4, False) == ("single", 0, N.GEN_PIPE)
     assert auto_plan(d5, 24, False) == ("grouped", 4, N.GEN_PIPE)
     assert auto_plan(d5, 25, False) == ("single", 0, N.GEN_GENERIC)

@@ -63,7 +63,9 @@ def test_conditioned_gradients_are_one_buffer_and_one_adamw_launch(monkeypatch):
             # kernels on the same inputs, equal up to the order of those additions
             assert (p.grad - q.grad).abs().max() <= 1e-4 * q.grad.abs().max().clamp_min(1e-30), k
         else:
-            assert torch.equal(p.grad, q.grad), k
+            # same kernels, same inputs; the small model's embedding gradient adds with float atomics
+            # when its table copies do not fit the scratch, so "equal" is up to the order of additions
+            assert (p.grad - q.grad).abs().max() <= 1e-6 * q.grad.abs().max().clamp_min(1e-30), k
     # the one-reduction gradient norm of the trainer == the per-parameter form (gaps are zero)
     per_param = torch.stack([p.grad.norm(2) for p in used]).norm(2)
     assert abs(float(span.norm(2)) - float(per_param)) <= 1e-6 * float(per_param)
