@@ -104,7 +104,8 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
 #define MVN_GEN_PIPE_F16 4 /* C=K=128, Q=256: the PIPE structure with FP16 OPERANDS and FP32
                               ACCUMULATION (BASELINE configs[4]; precedent: torch.autocast,
                               movenet/trainer.py:124): weights and every product's vector
-                              operand rounded to fp16, v_dot2c_f32_f16 sums in fp32; two layers
+                              operand rounded to fp16, sums in fp32 (v_mfma_f32_16x16x32_f16 in
+                              the layer stages, v_dot2c_f32_f16 in the head); two layers
                               per stage, ceil(L/2)+1 stages (31 for 60 layers: one XCD): 8
                               pipelines per launch, each serving up to 8 sequences in turn (64
                               per launch).  Never chosen by MVN_GEN_AUTO: fp32 is the default.   */

@@ -14,7 +14,9 @@
 //   * the vector operand of every product (residual stream, popped queue entry, context
 //     column, gated activation, head activations) is rounded to fp16 when it is written to
 //     LDS, and a lane reads its 64 inputs with 8 ds_read_b128 instead of 16;
-//   * products and sums run in v_dot2c_f32_f16: fp16 x fp16 products accumulated in fp32.
+//   * products and sums run in fp16 x fp16 -> fp32: v_mfma_f32_16x16x32_f16 in the layer stages (r3,
+//     the default: "fp16 MFMA 1x1 convs" as BASELINE configs[4] is written), v_dot2c_f32_f16 in the
+//     head and in the layer stages' dot-product form (MOVENET_H16_FORM=dot2).
 // Everything else stays fp32: the residual stream itself, the skip sum, the past-tap
 // partial sums, biases, gating, the embedding rows (a gather, no product), the dilation
 // queues in HBM/L2, logits and the double softmax.
@@ -117,7 +119,8 @@ __device__ __forceinline__ float pair_sum(float v) { return v + dpp_mov<DPP_XOR1
 
 // MULTI = false: one sequence per pipeline (nseq == nb).  MULTI = true: pipeline b serves sequences
 // b, b + nb, b + 2 nb, ... < nseq in turn.
-template <bool MULTI>
+// MFMA = true (r3): every product of a layer stage on the matrix cores (see the layer stage below).
+template <bool MULTI, bool MFMA>
 __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *hand, unsigned *err, int NS,
                                                              int nb, int nseq) {
   using namespace h16;
@@ -164,8 +167,227 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
     __syncthreads();
   }
 
-  if (s < NS - 1) {
-    // ================= layer stage: layers l0 .. l0+nl-1 =================
+  if (MFMA && s < NS - 1) {
+    // ================= layer stage, MATRIX-CORE form: layers l0 .. l0+nl-1 =================
+    // A mat-vec wastes 15 of an MFMA's 16 columns, and still: scripts/probes/h16_phase.hip times one
+    // 256 x 128 phase (vector reads, products, barrier) at 412 cycles with eight
+    // v_mfma_f32_16x16x32_f16 per wave against 464 (all waves) / 520 (one wave per SIMD, the form
+    // below) with v_dot2c -- and the matrix cores return every row's COMPLETE sum to a lane, so the
+    // DPP lane sums go as well.  (Half of the rows each way is slower than either: 545.)
+    // Wave w owns channels [16 w, 16 w + 16): four 16-row tiles per layer -- filter, gate, residual,
+    // skip -- x four k-steps of 32 inputs, the A operands in registers (lane l: row l % 16, inputs
+    // 32 kk + 8 (l / 16) .. + 8: 64 registers per layer, as many as the dot-product form); the B
+    // operand is the stage's vector in every column (lane l reads inputs 32 kk + 8 (l / 16) .. + 8:
+    // four ds_read_b128, the same for the 16 lanes of a row group); the accumulator of lane l holds
+    // rows 4 (l / 16) + r, r < 4, in every column: lane 16 q + r (r < 4) post-processes channel
+    // 16 w + 4 q + r -- gate, residual add, queue traffic, skip lane -- and is that channel's lead.
+    const int l0 = s * LPS, nl = min(LPS, L - l0);
+    const int q = lane >> 4, r4 = lane & 3;
+    const bool lead = (lane & 15) < 4;
+    const int c = 16 * wave + 4 * q + r4;                    // (every lane: the channel its row group's lane r4 leads)
+    h8 *wp = (h8 *)smem_b;                                   // [LPS][tile 2][kk 4][512] h8: past-tap f|g weights
+    float *cur = (float *)(smem_b + LPS * MAT_H * 2);        // [C] residual stream (fp32)
+    _Float16 *curh = (_Float16 *)(cur + 2 * C);              // [C] the stream as the products' operand
+    const u64 *skbox = inbox + C + c;                        // this channel's granule of the skip lane
+    _Float16 *zbh = curh + C;                                // [LPS][C] gated activations (kept for the skip tiles)
+    _Float16 *pasth = zbh + LPS * C;                         // [LPS][C] popped queue entries
+    _Float16 *ctxh = pasth + LPS * C;                        // [C] context column
+    float *ring = a.state + (size_t)b * a.state_per_seq;
+    auto bind = [&](int g) {  // MULTI: the pointers of sequence b + g nb
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      skbox = inbox + C + c;
+      ring = a.state + (size_t)bq * a.state_per_seq;
+    };
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    auto sel = [&](const f4v &v) { return r4 == 0 ? v[0] : r4 == 1 ? v[1] : r4 == 2 ? v[2] : v[3]; };
+    // a 16-row tile x 128 inputs against the vector at `xp` (halves in LDS): four MFMAs
+    auto tile = [&](const h8 (&w)[4], const h8 (&x)[4]) {
+      f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kk], x[kk], acc, 0, 0, 0);
+      return acc;
+    };
+    auto vec = [&](h8 (&x)[4], const _Float16 *xp) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) x[kk] = ((const h8 *)xp)[4 * kk + q];
+    };
+
+    h8 wF[LPS][4], wG[LPS][4], wR[LPS][4], wS[LPS][4];
+    float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
+    int doff[LPS], dmask[LPS];
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+      bias_r[j] = 0.f; bias_s[j] = 0.f; pf[j] = 0.f; pg[j] = 0.f; xs[j] = 0.f;
+      doff[j] = 0; dmask[j] = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        wF[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        wG[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        wR[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        wS[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      if (j < nl) {
+        const float *lw = a.w + EMB_F + (size_t)(l0 + j) * LAYER_F;
+        const h8 *wc8 = (const h8 *)lw, *wp8 = (const h8 *)(lw + MAT_F), *wr8 = (const h8 *)(lw + 2 * MAT_F);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {  // packed as [tile 2][kk 4][wave 8][lane 64] = [tile][kk][tid]
+          wF[j][kk] = wc8[kk * NT + tid];
+          wG[j][kk] = wc8[(4 + kk) * NT + tid];
+          wR[j][kk] = wr8[kk * NT + tid];
+          wS[j][kk] = wr8[(4 + kk) * NT + tid];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wp[(j * 8 + i) * NT + tid] = wp8[i * NT + tid];
+        bias_r[j] = lw[3 * MAT_F + c];
+        bias_s[j] = lw[3 * MAT_F + C + c];
+        const int l = l0 + j;
+        dmask[j] = (1 << (l % a.layer_size)) - 1;
+        doff[j] = ring_offset(l, a.layer_size, C);
+      }
+    }
+
+    // Off the critical path: queue push / pop (lead lanes), then the past-tap half of step tn's f/g
+    // sums: the same tiles, A operands streamed from LDS (context convs: from L2)
+    auto precompute = [&](int tn, bool push) {
+      int tq = tid;
+      asm volatile("" : "+v"(tq));  // addresses rebuilt per step: the chain needs the registers
+      const int lq = (tq >> 4) & 3, cq = 16 * (tq >> 6) + 4 * lq + (tq & 3);
+      if ((tq & 15) < 4) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) {
+            float *base = ring + doff[j] + cq;
+            if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
+            const float pv = (push && dmask[j] == 0) ? xs[j] : ring_load(base + (tn & dmask[j]) * C);
+            pasth[j * C + cq] = (_Float16)pv;
+          }
+      }
+      if (a.ctx_tm && tq < C) ctxh[tq] = (_Float16)a.ctx_tm[(size_t)bq * a.ctx_stride_b + (size_t)tn * C + tq];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < LPS; ++j)
+        if (j < nl) {
+          h8 x[4], w[4];
+          vec(x, pasth + j * C);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) w[kk] = wp[(j * 8 + kk) * NT + tq];
+          pf[j] = sel(tile(w, x));
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) w[kk] = wp[(j * 8 + 4 + kk) * NT + tq];
+          pg[j] = sel(tile(w, x));
+          __builtin_amdgcn_sched_barrier(0);
+          if (a.ctx_tm) {
+            // 1x1 context convs (modules.py:58-63, :75-77), weights streamed from L2
+            const float *wc = a.wctx + (size_t)(l0 + j) * CTX_LAYER_F;
+            vec(x, ctxh);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) w[kk] = ((const h8 *)wc)[kk * NT + tq];
+            pf[j] += sel(tile(w, x)) + wc[MAT_F + cq];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) w[kk] = ((const h8 *)wc)[(4 + kk) * NT + tq];
+            pg[j] += sel(tile(w, x)) + wc[MAT_F + C + cq];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    };
+    auto save_pf = [&](int g) {
+      if (MULTI && lead) *(f4 *)(pfs + ((size_t)g * C + c) * PFS_F) = f4{pf[0], pg[0], pf[1], pg[1]};
+    };
+    auto load_pf = [&](int g) {
+      if (MULTI) {
+        const f4 v = *(const f4 *)(pfs + ((size_t)g * C + c) * PFS_F);
+        pf[0] = v.x; pg[0] = v.y; pf[1] = v.z; pg[1] = v.w;
+      }
+    };
+    __syncthreads();
+    if (MULTI) {
+      for (int g = 0; g < G; ++g) {
+        bind(g);
+        precompute(a.t_begin, false);
+        save_pf(g);
+        __syncthreads();
+      }
+    } else {
+      precompute(a.t_begin, false);
+    }
+
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) bind(g);
+      const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
+      if (wave == 0) {
+        float v[GL];
+        const bool ok = wait_inbox<GL>(inbox, epoch, err, v);  // the C residual granules
+        if (ok) {
+          cur[2 * lane] = v[0];
+          cur[2 * lane + 1] = v[1];
+          *(h2 *)(curh + 2 * lane) = h2{(_Float16)v[0], (_Float16)v[1]};
+        }
+        if (lane == 0) iflag[0] = ok ? 1 : 0;
+      }
+      lds_barrier();
+      MVN_STAMP(b, s, ts - a.t_begin, 0);
+      load_pf(g);
+      const u64 sk_peek = lead ? peek_granule(skbox) : 0;  // skip lane: requested here, used at the hand-on
+      float skipacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < LPS; ++j)
+        if (j < nl) {
+          h8 x[4];
+          vec(x, curh);
+          const f4v aF = tile(wF[j], x), aG = tile(wG[j], x);
+          const float z = gate_fast(sel(aF) + pf[j], sel(aG) + pg[j]);
+          if (lead) zbh[j * C + c] = (_Float16)z;
+          const float old = cur[c];  // this layer's input: residual add below, queue push later
+          lds_barrier();
+          vec(x, zbh + j * C);
+          const f4v aR = tile(wR[j], x);  // (the skip tile is not on the chain: after the hand-on, below)
+          if (lead) {
+            xs[j] = old;
+            const float outv = (sel(aR) + bias_r[j]) + old;
+            cur[c] = outv;
+            curh[c] = (_Float16)outv;
+            // the stage's last layer: hand the activation on before anything else
+            if (j == nl - 1) put_granule(outbox + c, epoch, outv, fast_edge);
+          }
+          lds_barrier();
+        }
+      // ---- the skip lane, off the chain: sk' = sk + sum_j (Ws_j z_j + bs_j)
+#pragma unroll
+      for (int j = 0; j < LPS; ++j)
+        if (j < nl) {
+          h8 x[4];
+          vec(x, zbh + j * C);
+          skipacc += sel(tile(wS[j], x)) + bias_s[j];
+        }
+      if (lead) {
+        const float skin = (unsigned)(sk_peek >> 32) == epoch ? __uint_as_float((unsigned)sk_peek)
+                                                              : wait_granule(skbox, epoch, err);
+        put_granule(outbox + C + c, epoch, skin + skipacc, fast_edge);
+      }
+      MVN_STAMP(b, s, ts - a.t_begin, 1);
+      if (iflag[0] == 0) {  // hand-off timed out (checked after the step: off the chain)
+        alive = false;
+        break;
+      }
+      if (ts + 1 < a.t_end) {
+        precompute(ts + 1, true);
+        save_pf(g);
+      } else if (lead) {
+        // last step of the launch: push only (the next launch pops in its prologue)
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+          if (j < nl) ring[doff[j] + c + (ts & dmask[j]) * C] = xs[j];
+      }
+    }
+    return;
+  }
+
+  if (!MFMA && s < NS - 1) {
+    // ================= layer stage, dot-product form (r2 + the r3 skip lane): layers l0 .. l0+nl-1 =================
     const int l0 = s * LPS, nl = min(LPS, L - l0);
     const bool fg_group = tid < 256;
     const int t = tid & 255, c = t / KQ, kq = t % KQ;
@@ -516,21 +738,30 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
 // ---- packing: state_dict layouts (fp32) -> per-thread register order, halves ------------
 // each 2C x C matrix: [2*NV][t (256)] vectors of 8 halves; thread t = KQ*c + kq owns rows
 // (c, C+c) x inputs k = KPER*kq + 8*(iv % NV) + e: vectors 0..NV-1 row c, NV..2NV-1 row C+c
-__device__ __forceinline__ void h16_matrix_index(int h, int &row, int &k) {
+__device__ __forceinline__ void h16_matrix_index(int h, int &row, int &k, bool mfma) {
   using namespace h16;
-  const int e = h & 7, v = h >> 3, t = v & 255, iv = v >> 8;
+  const int e = h & 7, v = h >> 3;
+  if (mfma) {
+    // MFMA A-operand order: [tile 2][kk 4][wave 8][lane 64] vectors; lane l of wave w holds row
+    // 16 w + l % 16 of the tile's half (filter | gate, residual | skip), inputs 32 kk + 8 (l / 16) + e
+    const int l = v & 63, w = (v >> 6) & 7, kk = (v >> 9) & 3, t = v >> 11;
+    row = t * C + 16 * w + (l & 15);
+    k = 32 * kk + 8 * (l >> 4) + e;
+    return;
+  }
+  const int t = v & 255, iv = v >> 8;
   row = (iv / NV) * C + t / KQ;
   k = KPER * (t % KQ) + 8 * (iv % NV) + e;
 }
 __global__ void pack_layer_h16_kernel(const float *fw, const float *gw, const float *rw, const float *rb,
-                                      const float *sw, const float *sb, float *__restrict__ dst) {
+                                      const float *sw, const float *sb, float *__restrict__ dst, bool mfma) {
   using namespace h16;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // half index for the matrices
   _Float16 *dh = (_Float16 *)dst;
   if (i < 3 * MAT_H) {
     const int region = i / MAT_H;
     int row, k;
-    h16_matrix_index(i - region * MAT_H, row, k);
+    h16_matrix_index(i - region * MAT_H, row, k, mfma);
     const float v = region < 2 ? fg_elem(fw, gw, C, row, region == 0 ? C + k : k)  // WC current, WP past tap
                                : rs_elem(rw, sw, C, row, k);
     dh[i] = (_Float16)v;
@@ -540,13 +771,13 @@ __global__ void pack_layer_h16_kernel(const float *fw, const float *gw, const fl
   }
 }
 __global__ void pack_ctx_h16_kernel(const float *wcf, const float *bcf, const float *wcg, const float *bcg,
-                                    float *__restrict__ dst) {
+                                    float *__restrict__ dst, bool mfma) {
   using namespace h16;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   _Float16 *dh = (_Float16 *)dst;
   if (i < MAT_H) {
     int row, k;
-    h16_matrix_index(i, row, k);
+    h16_matrix_index(i, row, k, mfma);
     dh[i] = (_Float16)(row < C ? wcf[(size_t)row * C + k] : wcg[(size_t)(row - C) * C + k]);
   } else if (i < MAT_H + 2 * C) {
     const int o = i - MAT_H;
@@ -582,6 +813,16 @@ __global__ void pack_embed_h16_kernel(const float *__restrict__ causal_w, float 
   dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
 }
 
+// Which layer-stage form packs and runs: the matrix-core form unless MOVENET_H16_FORM=dot2 (the
+// packed weight order differs, so pack and launch read the same switch; read once per process).
+static bool h16_mfma_form() {
+  static const bool on = [] {
+    const char *e = getenv("MOVENET_H16_FORM");
+    return !(e && e[0] == 'd');
+  }();
+  return on;
+}
+
 bool pipe_h16_ok(const mvn_dims *d) {
   return d->residual_channels == 128 && d->skip_channels == 128 && d->input_channels == 256 &&
          n_layers(d) >= 1;
@@ -604,7 +845,7 @@ int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool ha
   for (int l = 0; l < L; ++l)
     hipLaunchKernelGGL(pack_layer_h16_kernel, dim3((3 * MAT_H + 2 * C + 255) / 256), dim3(256), 0, s,
                        p->filter_w[l], p->gate_w[l], p->residual_w[l], p->residual_b[l], p->skip_w[l],
-                       p->skip_b[l], packed + EMB_F + (size_t)l * LAYER_F);
+                       p->skip_b[l], packed + EMB_F + (size_t)l * LAYER_F, h16_mfma_form());
   float *head = packed + EMB_F + (size_t)L * LAYER_F;
   hipLaunchKernelGGL(pack_head_h16_kernel, dim3((Q * C + Q * Q + Q + 255) / 256), dim3(256), 0, s, p->head1_w,
                      p->head1_b, p->head2_w, p->head2_b, head);
@@ -613,7 +854,7 @@ int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool ha
     for (int l = 0; l < L; ++l)
       hipLaunchKernelGGL(pack_ctx_h16_kernel, dim3((MAT_H + 2 * C + 255) / 256), dim3(256), 0, s,
                          p->ctx_filter_w[l], p->ctx_filter_b[l], p->ctx_gate_w[l], p->ctx_gate_b[l],
-                         ctx + (size_t)l * CTX_LAYER_F);
+                         ctx + (size_t)l * CTX_LAYER_F, h16_mfma_form());
   }
   return check_hip(hipGetLastError(), "pipe_h16_pack");
 }
@@ -627,7 +868,9 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
   const int pipes = std::min(batch, pipe_h16_pipelines(d));
   const bool multi = batch > pipes;
   int dev = 0, cus = 0, per_cu = 0, coop = 0;
-  const void *fn = multi ? (const void *)gen_pipe_h16_kernel<true> : (const void *)gen_pipe_h16_kernel<false>;
+  const bool mm = h16_mfma_form();
+  const void *fn = multi ? (mm ? (const void *)gen_pipe_h16_kernel<true, true> : (const void *)gen_pipe_h16_kernel<true, false>)
+                         : (mm ? (const void *)gen_pipe_h16_kernel<false, true> : (const void *)gen_pipe_h16_kernel<false, false>);
   const int lds_bytes = multi ? LDS_BYTES_MULTI : LDS_BYTES;
   int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_pipe_h16)");
   if (rc) return rc;
@@ -665,10 +908,8 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
     return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(NT), kargs, (unsigned)lds_bytes, s),
                      "mvn_generate(pipe_f16, cooperative launch)");
   }
-  if (multi)
-    hipLaunchKernelGGL(gen_pipe_h16_kernel<true>, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb, nseq);
-  else
-    hipLaunchKernelGGL(gen_pipe_h16_kernel<false>, dim3(slots * 8), dim3(NT), lds_bytes, s, args, gran, err, NS, nb, nseq);
+  void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb, (void *)&nseq};
+  return check_hip(hipLaunchKernel(fn, dim3(slots * 8), dim3(NT), kargs, (size_t)lds_bytes, s), "mvn_generate(pipe_f16)");
   return check_hip(hipGetLastError(), "mvn_generate(pipe_f16)");
 }
 

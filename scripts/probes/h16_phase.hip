@@ -5,6 +5,10 @@
 //   mode 2: 8 v_mfma_f32_16x16x32_f16 per wave of all 8 waves (two chains of four k-steps)
 //   mode 3: mode 2 + the four ds_read_b128 of the operand vector
 //   mode 4: mode 1 + its four ds_read_b128
+//   mode 5: mode 3 / mode 4 half and half: four MFMAs + 16 v_dot2c per wave, all 8 waves (do the
+//           fp16 matrix cores run BESIDE the vector ALU?)
+//   mode 6: the same on waves 0-3 only (one wave per SIMD: eight MFMAs + 32 v_dot2c each)
+//   mode 7: waves 0-3 only, 64 v_dot2c each + the four ds_read_b128 (the r2 form, measured properly)
 // each repeated `iters` times between two barriers (the barrier pair is timed too).
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/h16_phase scripts/probes/h16_phase.hip && /tmp/h16_phase
 #include <hip/hip_runtime.h>
@@ -54,11 +58,41 @@ __global__ __launch_bounds__(512, 2) void probe(float *out, long long *cycles, i
         for (int e = 0; e < 4; ++e)
           acc[(i * 4 + e) & 7] = __builtin_amdgcn_fdot2(h2{w[i][2 * e], w[i][2 * e + 1]}, h2{x[i & 3][2 * e], x[i & 3][2 * e + 1]},
                                                        acc[(i * 4 + e) & 7], false);
-    } else {
+    } else if (MODE == 2 || MODE == 3) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[k], x[k], d0, 0, 0, 0);
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[4 + k], x[k], d1, 0, 0, 0);
+      }
+    } else if (MODE == 5) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[k], x[k], d0, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[e] = __builtin_amdgcn_fdot2(h2{w[4 + k][2 * e], w[4 + k][2 * e + 1]}, h2{x[k][2 * e], x[k][2 * e + 1]}, acc[e], false);
+      }
+    } else if (MODE == 6) {
+      if (wave < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[k], x[k], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[4 + k], x[k], d1, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[e] = __builtin_amdgcn_fdot2(h2{w[8 + k][2 * e], w[8 + k][2 * e + 1]}, h2{x[k][2 * e], x[k][2 * e + 1]}, acc[e], false);
+            acc[4 + e] = __builtin_amdgcn_fdot2(h2{w[12 + k][2 * e], w[12 + k][2 * e + 1]}, h2{x[k][2 * e], x[k][2 * e + 1]}, acc[4 + e], false);
+          }
+        }
+      }
+    } else if (MODE == 7) {
+      if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[(i * 4 + e) & 7] = __builtin_amdgcn_fdot2(h2{w[i][2 * e], w[i][2 * e + 1]}, h2{x[i & 3][2 * e], x[i & 3][2 * e + 1]},
+                                                         acc[(i * 4 + e) & 7], false);
       }
     }
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(d0), "+v"(d1));
@@ -95,5 +129,8 @@ int main() {
   run<2>("mode 2: 8 v_mfma_f32_16x16x32_f16 per wave, all 8 waves", out, cyc, iters);
   run<3>("mode 3: mode 2 + 4 ds_read_b128 of the vector", out, cyc, iters);
   run<4>("mode 4: mode 1 + 4 ds_read_b128 of the vector", out, cyc, iters);
+  run<5>("mode 5: 4 MFMA + 16 v_dot2c per wave, all 8 waves, + 4 ds_read_b128", out, cyc, iters);
+  run<6>("mode 6: 8 MFMA + 32 v_dot2c per wave, waves 0-3 only, + 4 ds_read_b128", out, cyc, iters);
+  run<7>("mode 7: 64 v_dot2c per wave, waves 0-3 only, + 4 ds_read_b128 (r2 form)", out, cyc, iters);
   return 0;
 }
