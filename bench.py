@@ -393,7 +393,7 @@ def config5_lines(dev, rank, n_new=22050):
                        "greedy generate of 22050 samples (1 s of audio)", "flop_per_sample": flop}
     for key, variant, peak, bound in (("fp32", N.GEN_PIPE, FP32_PEAK_TFLOPS, "valu_fp32"),
                                       ("fp16_operands_fp32_accumulate", N.GEN_PIPE_F16, FP16_DENSE_PEAK_TFLOPS,
-                                       "valu_fp16_dot2 (priced against the dense fp16 MATRIX peak)")):
+                                       "mfma_fp16 (useful FLOP against the dense fp16 matrix peak; a mat-vec fills 1 of an MFMA's 16 columns)")):
         g = RingGenerator(**CFG5, state_dict=sd5, batch=1, n_total=rf + n_new + n_new // 10 + 1, device=dev,
                           variant=variant, temperature=0.0, seed=0)
         g.prime(synthetic_indices(1, rf, 256, 1234 + rank).to(dev))

@@ -203,6 +203,8 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
     typedef float f4v __attribute__((ext_vector_type(4)));
     auto sel = [&](const f4v &v) { return r4 == 0 ? v[0] : r4 == 1 ? v[1] : r4 == 2 ? v[2] : v[3]; };
     // a 16-row tile x 128 inputs against the vector at `xp` (halves in LDS): four MFMAs
+    // (one accumulator over the four k-steps; two accumulators of two steps each measured no faster:
+    // the phase is not waiting for MFMA passes)
     auto tile = [&](const h8 (&w)[4], const h8 (&x)[4]) {
       f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -336,13 +338,16 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
 #pragma unroll
       for (int j = 0; j < LPS; ++j)
         if (j < nl) {
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 0, 0);
           h8 x[4];
           vec(x, curh);
           const f4v aF = tile(wF[j], x), aG = tile(wG[j], x);
           const float z = gate_fast(sel(aF) + pf[j], sel(aG) + pg[j]);
           if (lead) zbh[j * C + c] = (_Float16)z;
           const float old = cur[c];  // this layer's input: residual add below, queue push later
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 1, 0);
           lds_barrier();
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 0);
           vec(x, zbh + j * C);
           const f4v aR = tile(wR[j], x);  // (the skip tile is not on the chain: after the hand-on, below)
           if (lead) {
@@ -353,7 +358,10 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
             // the stage's last layer: hand the activation on before anything else
             if (j == nl - 1) put_granule(outbox + c, epoch, outv, fast_edge);
           }
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 0);
+          if (j == nl - 1) MVN_FINE(b, s, ts - a.t_begin, 5, 0);
           lds_barrier();
+          if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 4, 0);
         }
       // ---- the skip lane, off the chain: sk' = sk + sum_j (Ws_j z_j + bs_j)
 #pragma unroll
@@ -914,3 +922,14 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
 }
 
 }  // namespace mvn
+
+#ifdef MVN_PIPE_STAMPS
+extern "C" int mvn_debug_read_stamps_h16(unsigned long long *out, size_t n) {
+  if (n > sizeof(mvn::g_stamps) / 8) n = sizeof(mvn::g_stamps) / 8;
+  return mvn::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(mvn::g_stamps), n * 8), "read stamps");
+}
+extern "C" int mvn_debug_read_fine_h16(unsigned long long *out, size_t n) {
+  if (n > sizeof(mvn::g_fine) / 8) n = sizeof(mvn::g_fine) / 8;
+  return mvn::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(mvn::g_fine), n * 8), "read fine");
+}
+#endif

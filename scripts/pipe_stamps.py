@@ -19,7 +19,8 @@ from movenet_amd import _native as N  # noqa: E402
 from movenet_amd.generation import RingGenerator  # noqa: E402
 from movenet_amd.utils.weights import make_state_dict, synthetic_indices  # noqa: E402
 
-WIDE = "--c128" in sys.argv    # BASELINE config 5: 61 stages, the stamps cover the first 16
+H16 = "--h16" in sys.argv      # config 5 with fp16 operands: 31 stages, the stamps cover the first 16
+WIDE = "--c128" in sys.argv or H16   # BASELINE config 5: 61 stages, the stamps cover the first 16
 FOLD = "--fold" in sys.argv    # the FOLD variant (11 stages of three folded layers)
 if WIDE:
     CFG = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
@@ -30,15 +31,15 @@ else:
 dev = "cuda:0"
 sd = {k: v.to(dev) for k, v in make_state_dict(**CFG, seed=0).items()}
 g = RingGenerator(**CFG, state_dict=sd, batch=B, n_total=rf + 4000, device=dev,
-                  variant=N.GEN_FOLD if FOLD else N.GEN_PIPE)
+                  variant=N.GEN_PIPE_F16 if H16 else N.GEN_FOLD if FOLD else N.GEN_PIPE)
 g.prime(synthetic_indices(B, rf, 256, 1234).to(dev))
 g.advance(1000)
 g.advance(1000)
 g.check_errors()
 lib = N.lib()
 buf = np.zeros((16, 16, 64, 4), dtype=np.uint64)
-read_stamps = lib.mvn_debug_read_stamps_fold if FOLD else lib.mvn_debug_read_stamps
-read_fine = lib.mvn_debug_read_fine_fold if FOLD else lib.mvn_debug_read_fine
+read_stamps = lib.mvn_debug_read_stamps_h16 if H16 else lib.mvn_debug_read_stamps_fold if FOLD else lib.mvn_debug_read_stamps
+read_fine = lib.mvn_debug_read_fine_h16 if H16 else lib.mvn_debug_read_fine_fold if FOLD else lib.mvn_debug_read_fine
 read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert read_stamps(buf.ctypes.data, buf.size) == 0
 NS = 16 if WIDE else (11 if FOLD else 9)          # stages looked at
@@ -74,7 +75,14 @@ print("sum compute %.2f us, sum hops %.2f us" % (compute.mean(0).mean(1).sum() +
 
 fine = np.zeros((16, 16, 64, 8), dtype=np.uint64)
 read_fine.argtypes = [C.c_void_p, C.c_size_t]
-if FOLD and read_fine(fine.ctypes.data, fine.size) == 0:
+if H16 and read_fine(fine.ctypes.data, fine.size) == 0:
+    f = fine[:B, :NS - 1, 8:, :6].astype(np.int64)
+    print("a stage of gen_pipe_h16_kernel (MFMA form), shader cycles (median over stages, steps, sequences; lane 0 of wave 0):")
+    for nm, i0, i1 in (("layer 0 filter/gate phase (vector reads, 8 MFMAs, gate, z write)", 0, 1), ("barrier", 1, 2),
+                       ("layer 0 residual phase (vector reads, 4 MFMAs, stream update)", 2, 3), ("barrier", 3, 4),
+                       ("layer 1: both phases and their barrier, up to the hand-on", 4, 5), ("stage: first phase start -> hand-on", 0, 5)):
+        print(f"  {nm:52s} {np.median(f[..., i1] - f[..., i0]):7.0f}")
+elif FOLD and read_fine(fine.ctypes.data, fine.size) == 0:
     f = fine[:B, :NS - 1, 8:, :].astype(np.int64)
     seg = [("phase 0 chain work (xp, zl dots, gate, z0 write)", 0, 1), ("phase 0 helper work (thread 256)", 0, 6),
            ("phase 0 incl. barrier", 0, 2), ("phase 1 chain work", 2, 3), ("phase 1 helper work", 2, 7),

@@ -9,6 +9,8 @@
 //           fp16 matrix cores run BESIDE the vector ALU?)
 //   mode 6: the same on waves 0-3 only (one wave per SIMD: eight MFMAs + 32 v_dot2c each)
 //   mode 7: waves 0-3 only, 64 v_dot2c each + the four ds_read_b128 (the r2 form, measured properly)
+//   mode 8: waves 0-3 eight MFMAs each (half of the rows), waves 4-7 32 v_dot2c each (the other half):
+//           one MFMA wave and one VALU wave per SIMD -- do the two pipes run side by side ACROSS waves?
 // each repeated `iters` times between two barriers (the barrier pair is timed too).
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/h16_phase scripts/probes/h16_phase.hip && /tmp/h16_phase
 #include <hip/hip_runtime.h>
@@ -85,6 +87,21 @@ __global__ __launch_bounds__(512, 2) void probe(float *out, long long *cycles, i
           }
         }
       }
+    } else if (MODE == 8) {
+      if (wave < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[k], x[k], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[4 + k], x[k], d1, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[(i * 4 + e) & 7] = __builtin_amdgcn_fdot2(h2{w[i][2 * e], w[i][2 * e + 1]}, h2{x[i & 3][2 * e], x[i & 3][2 * e + 1]},
+                                                         acc[(i * 4 + e) & 7], false);
+      }
     } else if (MODE == 7) {
       if (wave < 4) {
 #pragma unroll
@@ -132,5 +149,6 @@ int main() {
   run<5>("mode 5: 4 MFMA + 16 v_dot2c per wave, all 8 waves, + 4 ds_read_b128", out, cyc, iters);
   run<6>("mode 6: 8 MFMA + 32 v_dot2c per wave, waves 0-3 only, + 4 ds_read_b128", out, cyc, iters);
   run<7>("mode 7: 64 v_dot2c per wave, waves 0-3 only, + 4 ds_read_b128 (r2 form)", out, cyc, iters);
+  run<8>("mode 8: waves 0-3 8 MFMA, waves 4-7 32 v_dot2c (half the rows each), + reads", out, cyc, iters);
   return 0;
 }
