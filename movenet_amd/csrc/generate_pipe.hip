@@ -202,13 +202,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
 
     for (int ts = a.t_begin; ts < a.t_end; ++ts) {
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
-      // C = 64: the step starts as soon as the 64 residual-stream granules are in; the running
-      // skip sum (sent a little later by the producer, see below) is awaited by wave 4 while
-      // the filter/gate waves already work on the first layer.  C = 128: one wait for both.
-      constexpr bool SPLIT = CC == 64;
+      // The step starts as soon as the C residual-stream granules are in; the running skip sum
+      // (sent a little later by the producer, see below) is awaited by wave 4 while the filter/gate
+      // waves already work on the first layer.  (r3: C = 128 too -- one 16-byte poll per lane through
+      // poll16 instead of the two-load spin loop over 2C granules, and only the residual row of the
+      // residual|skip product on the chain.)
+      constexpr bool SPLIT = true;
       if (wave == 0) {
         bool ok;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && CC == 128) {
+          float v[2];
+          ok = wait_inbox<2>(inbox, epoch, err, v);
+          if (ok) {
+            cur[2 * lane] = v[0];
+            cur[2 * lane + 1] = v[1];
+          }
+        } else if constexpr (SPLIT) {
           float v[2];
           ok = wait_inbox64(inbox, epoch, err, v);
           if (ok && lane < 32) {
@@ -233,10 +242,19 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
       if constexpr (SPLIT) {
         if (wave == 4) {  // off the chain: the residual/skip waves idle during the first f/g phase
           float v[2];
-          const bool ok = wait_inbox64(inbox + C, epoch, err, v);
-          if (ok && lane < 32) {
-            skin[2 * lane] = v[0];
-            skin[2 * lane + 1] = v[1];
+          bool ok;
+          if constexpr (CC == 128) {
+            ok = wait_inbox<2>(inbox + C, epoch, err, v);
+            if (ok) {
+              skin[2 * lane] = v[0];
+              skin[2 * lane + 1] = v[1];
+            }
+          } else {
+            ok = wait_inbox64(inbox + C, epoch, err, v);
+            if (ok && lane < 32) {
+              skin[2 * lane] = v[0];
+              skin[2 * lane + 1] = v[1];
+            }
           }
           if (lane == 0) iflag[1] = ok ? 1 : 0;
         }
@@ -268,12 +286,17 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
             // Only the residual row is on the chain: it is finished and published first; the
             // skip row (same z, kept in registers) follows behind the barrier, while the
             // filter/gate waves are already on the next layer.
-            f4 xz[NF4];
+            f4 xz[CC == 64 ? NF4 : 1];  // C = 64: z stays in registers for the skip row; C = 128: re-read
             if (!fg_group) {
               if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 2, 256);
               if (j == 0 && lead) skipacc = skin[c];  // wave 4 stored it before this barrier
-              ldsn<NF4>(xz, zb + KPER * kq);
-              const float r = chan_sum<KQ>(dotn<NF4>(wa[j], xz));
+              float r;
+              if constexpr (CC == 64) {
+                ldsn<NF4>(xz, zb + KPER * kq);
+                r = chan_sum<KQ>(dotn<NF4>(wa[j], xz));
+              } else {
+                r = chan_sum<KQ>(dot1_lds<NF4>(wa[j], zb + KPER * kq));
+              }
               if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 3, 256);
               if (lead) {
                 xs[j] = old;
@@ -285,7 +308,10 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
             }
             lds_barrier();
             if (!fg_group) {
-              const float k = chan_sum<KQ>(dotn<NF4>(wb[j], xz));
+              // (C = 128: one layer per stage, so zb is untouched until the next step's first phase)
+              float k;
+              if constexpr (CC == 64) k = chan_sum<KQ>(dotn<NF4>(wb[j], xz));
+              else k = chan_sum<KQ>(dot1_lds<NF4>(wb[j], zb + KPER * kq));
               if (lead) {
                 skipacc += k + bias_s[j];
                 if (j == nl - 1) put_granule(outbox + C + c, epoch, skipacc, fast_edge);

@@ -350,6 +350,34 @@ __device__ __forceinline__ void dot2_lds(const v2f (&wa)[2 * N4], const v2f (&wb
   ra = ta.x + ta.y;
   rb = tb.x + tb.y;
 }
+// one row of dot2_lds (same chunking, same accumulation order as its `a` half)
+template <int N4>
+__device__ __forceinline__ float dot1_lds(const v2f (&wa)[2 * N4], const float *xp) {
+  constexpr int CH = 4, NCH = N4 / CH;
+  static_assert(N4 % CH == 0, "whole chunks");
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+  f4 x[N4];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) x[i] = ((const f4 *)xp)[i];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) {
+#pragma unroll
+      for (int i = CH * (ch + 1); i < CH * (ch + 2); ++i) x[i] = ((const f4 *)xp)[i];
+    }
+    if (NCH > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = CH * ch; i < CH * (ch + 1); i += 2) {
+      a0 = __builtin_elementwise_fma(wa[2 * i], v2f{x[i].x, x[i].y}, a0);
+      a1 = __builtin_elementwise_fma(wa[2 * i + 1], v2f{x[i].z, x[i].w}, a1);
+      a2 = __builtin_elementwise_fma(wa[2 * i + 2], v2f{x[i + 1].x, x[i + 1].y}, a2);
+      a3 = __builtin_elementwise_fma(wa[2 * i + 3], v2f{x[i + 1].z, x[i + 1].w}, a3);
+    }
+    if (NCH > 1) __builtin_amdgcn_sched_barrier(0);
+  }
+  const v2f ta = (a0 + a2) + (a1 + a3);
+  return ta.x + ta.y;
+}
 // dotn() with the weights fetched on the fly (LDS or L2), four float4 at a time so that
 // only 32 registers are live; same accumulators and order as dotn: bit-identical to it
 template <int N4>
