@@ -686,6 +686,15 @@ def main():
                 "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",
             },
         }
+        if extras and isinstance(extras.get("batch_sweep"), dict) and "error" not in extras["batch_sweep"]:
+            # 16 sequences IS the headline (not launched a second time: see batch_sweep_lines)
+            extras["batch_sweep"] = {"16": {"samples_per_s": value / world, "us_per_step_of_all_sequences":
+                                            elapsed / K / n_new * 1e6, "plan": ["single", 0, variant_used],
+                                            "roofline": {"bound": "valu_fp32", "achieved": achieved,
+                                                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                         "frac": achieved / FP32_PEAK_TFLOPS},
+                                            "note": "the headline's own timed steps"},
+                                     **extras["batch_sweep"]}
         out["train_step"] = train
         out["train_step_config3"] = train3
         out["trainer_fit"] = fit

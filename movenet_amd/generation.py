@@ -24,10 +24,14 @@ def wait_event(event, spin_s: float = 5.0) -> None:
     milliseconds of a step costs nothing that matters: one process drives one GPU)."""
     import time
     t0 = time.perf_counter()
+    spins = 0
     while not event.query():
-        if time.perf_counter() - t0 > spin_s:
-            event.synchronize()
-            return
+        spins += 1
+        if spins > 200:
+            time.sleep(20e-6)
+            if time.perf_counter() - t0 > spin_s:
+                event.synchronize()
+                return
 
 
 class HostWords:
@@ -70,9 +74,16 @@ class HostWords:
         import time
         slot, n, seq, words = token
         t0 = time.perf_counter()
+        spins = 0
         while int(slot[n]) != seq:
-            if time.perf_counter() - t0 > timeout_s:  # (never seen: the blocking form as a last resort)
-                return words.tolist()
+            spins += 1
+            if spins > 200:
+                # (a read that is not there after ~100 us is waiting for milliseconds of GPU work that
+                # the caller has overlapped with its own: yield the core between polls -- eight ranks
+                # of a node spinning flat out would eat eight cores of the container's quota)
+                time.sleep(20e-6)
+                if time.perf_counter() - t0 > timeout_s:  # (never seen: the blocking form as a last resort)
+                    return words.tolist()
         vals = slot[:n]
         return vals.tolist() if words.dtype == torch.int32 else vals.view(torch.float32).tolist()
 
