@@ -35,7 +35,15 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));  // 16 bytes
 
 namespace h16 {
 constexpr int C = 128, Q = 256, NT = 512;
-constexpr int LPS = 2;              // layers per stage
+constexpr int LPS = 2;              // layers per stage, dot-product form
+// layers per stage, matrix-core form: THREE when a pipeline serves one sequence (21 stages instead of
+// 31: ten hops less on the chain; the third layer's past taps and the skip tiles stream from L2
+// behind the hand-on), two when it serves several in turn (there the stages' service time per turn
+// is what bounds the step, and L2 streaming per turn costs more than ten hops save)
+template <bool MULTI>
+struct LpsM {
+  static constexpr int value = MULTI ? 2 : 3;
+};
 constexpr int KQ = 2;               // lanes sharing one channel's two rows
 constexpr int KPER = C / KQ;        // 64 inputs per lane
 constexpr int NV = KPER / 8;        // 8 h8 vectors per row per lane
@@ -56,7 +64,12 @@ constexpr int LDS_BYTES = LPS * MAT_H * 2 + 8192;
 // f/g sums (pf, pg of the LPS layers: four floats per channel), kept in LDS behind the vectors
 constexpr int GMAX = 8;
 constexpr int PFS_F = 2 * LPS;      // floats per channel and sequence
+constexpr int PFS_FM = PFS_F;       // ... matrix-core form (two layers per stage when MULTI)
 constexpr int LDS_BYTES_MULTI = LDS_BYTES + GMAX * C * PFS_F * 4;
+// matrix-core form: two layers' past taps in LDS (a third streams from L2) + 4 KB of vectors
+constexpr int LDS_BYTES_M = 2 * MAT_H * 2 + 4096;
+constexpr int LDS_BYTES_M_MULTI = LDS_BYTES_M + GMAX * C * PFS_FM * 4;
+static_assert(LDS_BYTES_M_MULTI <= 160 * 1024 && LDS_BYTES_MULTI <= 160 * 1024, "one CU's LDS");
 }  // namespace h16
 
 __device__ __forceinline__ float dot8(const h8 w, const h8 x, float acc) {
@@ -147,8 +160,9 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
   int bq = b;                                           // the sequence whose turn it is
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
   u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
-  int *iflag = (int *)(smem_b + LDS_BYTES - 64);  // [0] ok flag, [3] fast-edge flag
-  float *pfs = (float *)(smem_b + LDS_BYTES);     // MULTI: [GMAX][C][PFS_F] (layer stages), head: indices
+  constexpr int LDSB = MFMA ? LDS_BYTES_M : LDS_BYTES;
+  int *iflag = (int *)(smem_b + LDSB - 64);  // [0] ok flag, [3] fast-edge flag
+  float *pfs = (float *)(smem_b + LDSB);     // MULTI: [GMAX][C][PFS_F(M)] (layer stages), head: indices
   bool fast_edge = false;
   {
     unsigned *xcc = err + 16;
@@ -181,17 +195,22 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
     // four ds_read_b128, the same for the 16 lanes of a row group); the accumulator of lane l holds
     // rows 4 (l / 16) + r, r < 4, in every column: lane 16 q + r (r < 4) post-processes channel
     // 16 w + 4 q + r -- gate, residual add, queue traffic, skip lane -- and is that channel's lead.
-    const int l0 = s * LPS, nl = min(LPS, L - l0);
+    constexpr int LPSM = LpsM<MULTI>::value;
+    constexpr bool WS_REG = LPSM == 2;  // the skip tiles in registers (two layers) or streamed from L2 (three)
+    const int l0 = s * LPSM, nl = min(LPSM, L - l0);
     const int q = lane >> 4, r4 = lane & 3;
     const bool lead = (lane & 15) < 4;
     const int c = 16 * wave + 4 * q + r4;                    // (every lane: the channel its row group's lane r4 leads)
-    h8 *wp = (h8 *)smem_b;                                   // [LPS][tile 2][kk 4][512] h8: past-tap f|g weights
-    float *cur = (float *)(smem_b + LPS * MAT_H * 2);        // [C] residual stream (fp32)
+    // past-tap f|g weights: the first LPW layers' in LDS ([LPW][tile 2][kk 4][512] h8), the third
+    // layer's streamed from L2 (off the chain: 64 KB per step of a stage that idles 35 us of it)
+    constexpr int LPW = 2;
+    h8 *wp = (h8 *)smem_b;
+    float *cur = (float *)(smem_b + LPW * MAT_H * 2);        // [C] residual stream (fp32)
     _Float16 *curh = (_Float16 *)(cur + 2 * C);              // [C] the stream as the products' operand
     const u64 *skbox = inbox + C + c;                        // this channel's granule of the skip lane
-    _Float16 *zbh = curh + C;                                // [LPS][C] gated activations (kept for the skip tiles)
-    _Float16 *pasth = zbh + LPS * C;                         // [LPS][C] popped queue entries
-    _Float16 *ctxh = pasth + LPS * C;                        // [C] context column
+    _Float16 *zbh = curh + C;                                // [LPSM][C] gated activations (kept for the skip tiles)
+    _Float16 *pasth = zbh + LPSM * C;                         // [LPSM][C] popped queue entries
+    _Float16 *ctxh = pasth + LPSM * C;                        // [C] context column
     float *ring = a.state + (size_t)b * a.state_per_seq;
     auto bind = [&](int g) {  // MULTI: the pointers of sequence b + g nb
       bq = b + g * nb;
@@ -216,11 +235,13 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       for (int kk = 0; kk < 4; ++kk) x[kk] = ((const h8 *)xp)[4 * kk + q];
     };
 
-    h8 wF[LPS][4], wG[LPS][4], wR[LPS][4], wS[LPS][4];
-    float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
-    int doff[LPS], dmask[LPS];
+    // (the skip tiles are not on the chain: with three layers per stage their 48 registers are what
+    // does not fit -- they then stream from L2 behind the hand-on, 96 KB per step of a stage)
+    h8 wF[LPSM][4], wG[LPSM][4], wR[LPSM][4], wS[WS_REG ? LPSM : 1][4];
+    float bias_r[LPSM], bias_s[LPSM], pf[LPSM], pg[LPSM], xs[LPSM];
+    int doff[LPSM], dmask[LPSM];
 #pragma unroll
-    for (int j = 0; j < LPS; ++j) {
+    for (int j = 0; j < LPSM; ++j) {
       bias_r[j] = 0.f; bias_s[j] = 0.f; pf[j] = 0.f; pg[j] = 0.f; xs[j] = 0.f;
       doff[j] = 0; dmask[j] = 0;
 #pragma unroll
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
         wF[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         wG[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         wR[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        wS[j][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (WS_REG) wS[WS_REG ? j : 0][kk] = h8{0, 0, 0, 0, 0, 0, 0, 0};
       }
       if (j < nl) {
         const float *lw = a.w + EMB_F + (size_t)(l0 + j) * LAYER_F;
@@ -238,10 +259,12 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
           wF[j][kk] = wc8[kk * NT + tid];
           wG[j][kk] = wc8[(4 + kk) * NT + tid];
           wR[j][kk] = wr8[kk * NT + tid];
-          wS[j][kk] = wr8[(4 + kk) * NT + tid];
+          if (WS_REG) wS[WS_REG ? j : 0][kk] = wr8[(4 + kk) * NT + tid];
         }
+        if (j < LPW) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wp[(j * 8 + i) * NT + tid] = wp8[i * NT + tid];
+          for (int i = 0; i < 8; ++i) wp[(j * 8 + i) * NT + tid] = wp8[i * NT + tid];
+        }
         bias_r[j] = lw[3 * MAT_F + c];
         bias_s[j] = lw[3 * MAT_F + C + c];
         const int l = l0 + j;
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       const int lq = (tq >> 4) & 3, cq = 16 * (tq >> 6) + 4 * lq + (tq & 3);
       if ((tq & 15) < 4) {
 #pragma unroll
-        for (int j = 0; j < LPS; ++j)
+        for (int j = 0; j < LPSM; ++j)
           if (j < nl) {
             float *base = ring + doff[j] + cq;
             if (push) base[((tn - 1) & dmask[j]) * C] = xs[j];
@@ -269,15 +292,18 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       if (a.ctx_tm && tq < C) ctxh[tq] = (_Float16)a.ctx_tm[(size_t)bq * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < LPS; ++j)
+      for (int j = 0; j < LPSM; ++j)
         if (j < nl) {
           h8 x[4], w[4];
           vec(x, pasth + j * C);
+          // (layers beyond the LDS-resident ones: their past-tap weights come from the packed blob)
+          const h8 *wsrc = j < LPW ? (const h8 *)(wp + j * 8 * NT)
+                                   : (const h8 *)(a.w + EMB_F + (size_t)(l0 + j) * LAYER_F + MAT_F);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) w[kk] = wp[(j * 8 + kk) * NT + tq];
+          for (int kk = 0; kk < 4; ++kk) w[kk] = wsrc[kk * NT + tq];
           pf[j] = sel(tile(w, x));
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) w[kk] = wp[(j * 8 + 4 + kk) * NT + tq];
+          for (int kk = 0; kk < 4; ++kk) w[kk] = wsrc[(4 + kk) * NT + tq];
           pg[j] = sel(tile(w, x));
           __builtin_amdgcn_sched_barrier(0);
           if (a.ctx_tm) {
@@ -295,12 +321,21 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
         }
     };
     auto save_pf = [&](int g) {
-      if (MULTI && lead) *(f4 *)(pfs + ((size_t)g * C + c) * PFS_F) = f4{pf[0], pg[0], pf[1], pg[1]};
+      if (MULTI && lead) {
+        v2f *q2 = (v2f *)(pfs + ((size_t)g * C + c) * PFS_FM);
+#pragma unroll
+        for (int j = 0; j < LPSM; ++j) q2[j] = v2f{pf[j], pg[j]};
+      }
     };
     auto load_pf = [&](int g) {
       if (MULTI) {
-        const f4 v = *(const f4 *)(pfs + ((size_t)g * C + c) * PFS_F);
-        pf[0] = v.x; pg[0] = v.y; pf[1] = v.z; pg[1] = v.w;
+        const v2f *q2 = (const v2f *)(pfs + ((size_t)g * C + c) * PFS_FM);
+#pragma unroll
+        for (int j = 0; j < LPSM; ++j) {
+          const v2f v = q2[j];
+          pf[j] = v.x;
+          pg[j] = v.y;
+        }
       }
     };
     __syncthreads();
@@ -336,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       const u64 sk_peek = lead ? peek_granule(skbox) : 0;  // skip lane: requested here, used at the hand-on
       float skipacc = 0.f;
 #pragma unroll
-      for (int j = 0; j < LPS; ++j)
+      for (int j = 0; j < LPSM; ++j)
         if (j < nl) {
           if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 0, 0);
           h8 x[4];
@@ -365,11 +400,21 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
         }
       // ---- the skip lane, off the chain: sk' = sk + sum_j (Ws_j z_j + bs_j)
 #pragma unroll
-      for (int j = 0; j < LPS; ++j)
+      for (int j = 0; j < LPSM; ++j)
         if (j < nl) {
           h8 x[4];
           vec(x, zbh + j * C);
-          skipacc += sel(tile(wS[j], x)) + bias_s[j];
+          if (WS_REG) {
+            skipacc += sel(tile(wS[WS_REG ? j : 0], x)) + bias_s[j];
+          } else {
+            h8 w[4];
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const h8 *ws8 = (const h8 *)(a.w + EMB_F + (size_t)(l0 + j) * LAYER_F + 2 * MAT_F);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) w[kk] = ws8[(4 + kk) * NT + tq];
+            skipacc += sel(tile(w, x)) + bias_s[j];
+          }
         }
       if (lead) {
         const float skin = (unsigned)(sk_peek >> 32) == epoch ? __uint_as_float((unsigned)sk_peek)
@@ -387,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_h16_kernel(GenArgs a, u64 *ha
       } else if (lead) {
         // last step of the launch: push only (the next launch pops in its prologue)
 #pragma unroll
-        for (int j = 0; j < LPS; ++j)
+        for (int j = 0; j < LPSM; ++j)
           if (j < nl) ring[doff[j] + c + (ts & dmask[j]) * C] = xs[j];
       }
     }
@@ -835,6 +880,7 @@ bool pipe_h16_ok(const mvn_dims *d) {
   return d->residual_channels == 128 && d->skip_channels == 128 && d->input_channels == 256 &&
          n_layers(d) >= 1;
 }
+// stages per pipeline for SIZING (hand-off area, co-residency): the two-layer forms' count, the larger one
 int pipe_h16_stages(const mvn_dims *d) { return (n_layers(d) + h16::LPS - 1) / h16::LPS + 1; }
 int pipe_h16_pipelines(const mvn_dims *d) {  // co-resident pipelines
   const int NS = pipe_h16_stages(d);
@@ -872,14 +918,16 @@ int pipe_h16_pack(const mvn_dims *d, const mvn_params *p, float *packed, bool ha
 int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_total,
                     size_t status_off, hipStream_t s) {
   using namespace h16;
-  int NS = pipe_h16_stages(d);
   const int pipes = std::min(batch, pipe_h16_pipelines(d));
   const bool multi = batch > pipes;
   int dev = 0, cus = 0, per_cu = 0, coop = 0;
   const bool mm = h16_mfma_form();
+  // (a pipeline that serves one sequence runs three layers per stage in the matrix-core form)
+  const int lps = mm ? (multi ? LpsM<true>::value : LpsM<false>::value) : LPS;
+  int NS = (n_layers(d) + lps - 1) / lps + 1;
   const void *fn = multi ? (mm ? (const void *)gen_pipe_h16_kernel<true, true> : (const void *)gen_pipe_h16_kernel<true, false>)
                          : (mm ? (const void *)gen_pipe_h16_kernel<false, true> : (const void *)gen_pipe_h16_kernel<false, false>);
-  const int lds_bytes = multi ? LDS_BYTES_MULTI : LDS_BYTES;
+  const int lds_bytes = mm ? (multi ? LDS_BYTES_M_MULTI : LDS_BYTES_M) : (multi ? LDS_BYTES_MULTI : LDS_BYTES);
   int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_pipe_h16)");
   if (rc) return rc;
   if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||

@@ -21,7 +21,7 @@ flop_per_sample = 2 * (60 * (5 * 128 * 128 + 128 * 128) + 128 * 256 + 256 * 256)
 out = {}
 FP16_ONLY = "--fp16-only" in sys.argv
 for name, variant, batches in (("fp32 (gen_pipe_kernel<128>, 61 stages)", N.GEN_PIPE, (1, 4)),
-                               ("fp16 operands / fp32 accumulate (gen_pipe_h16_kernel, 31 stages)", N.GEN_PIPE_F16, (1, 4, 8, 16, 64)),
+                               ("fp16 operands / fp32 accumulate (gen_pipe_h16_kernel, 21 stages; 31 beyond 8 sequences)", N.GEN_PIPE_F16, (1, 4, 8, 16, 64)),
                                ("fp32 generic kernel", N.GEN_GENERIC, (1,))):
     for B in batches:
         if FP16_ONLY and (variant != N.GEN_PIPE_F16 or B != 1):
