@@ -472,6 +472,8 @@ def extra_lines(dev, sd, rf, n_new, rank):
     out["end_to_end_generate_ms"] = dt * 1e3
     out["end_to_end_fallback_variant"] = model.last_generate_fallback
     del model, audio, y
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return out  # (single-GPU figures: the other ranks of a multi-GPU run should not wait for them)
     for key, fn in (("batch_sweep", lambda: batch_sweep_lines(dev, sd, rf, rank)),
                     ("config3_generate", lambda: config3_generate_line(dev, rank)),
                     ("config5", lambda: config5_lines(dev, rank))):
