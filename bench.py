@@ -404,6 +404,17 @@ def config5_lines(dev, rank, n_new=22050):
                     "kernel_variant": g.variant,
                     "roofline": {"bound": bound, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}}
         del g
+        # ... and 16 sequences for throughput: the pipelines serve them in turn within ONE launch
+        B, n16 = 16, 4000
+        g = RingGenerator(**CFG5, state_dict=sd5, batch=B, n_total=rf + n16 + n16 // 10 + 1, device=dev,
+                          variant=variant, temperature=0.0, seed=0)
+        g.prime(synthetic_indices(B, rf, 256, 4321 + rank).to(dev))
+        dt, ms = timed_advance(g, dev, n16, n16 // 10)
+        tf = flop * B * n16 / (ms / 1e3) / 1e12
+        out[key]["batch_16"] = {"us_per_step_of_all_sequences": dt / n16 * 1e6, "samples_per_s": B * n16 / dt,
+                                "roofline": {"bound": bound, "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                                             "frac": tf / peak}}
+        del g
     return out
 
 

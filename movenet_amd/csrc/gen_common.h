@@ -61,7 +61,8 @@ __device__ __forceinline__ float rs_elem(const float *rw, const float *sw, int C
 bool pipe_ok(const mvn_dims *d);
 int pipe_stages(const mvn_dims *d);
 size_t pipe_hand_floats(const mvn_dims *d, int batch);  // hand-off area appended to the state
-int pipe_max_batch(const mvn_dims *d);                   // sequences that fit co-resident (256 CUs)
+int pipe_pipelines(const mvn_dims *d);                   // pipelines that fit co-resident (256 CUs)
+int pipe_max_batch(const mvn_dims *d);                   // ... each serving up to PipeCfg::GMAX sequences in turn
 size_t pipe_weights_floats(const mvn_dims *d);          // packed blob without the context section
 int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);
 int pipe_pack_ctx(const mvn_dims *d, const mvn_params *p, float *ctx_section, hipStream_t s);

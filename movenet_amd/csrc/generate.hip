@@ -746,8 +746,9 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   const bool fold_fits =
       mvn::fold_ok(dims) && batch >= 1 && device_cus() >= 256 && batch <= mvn::fold_max_batch(dims);
   if (requested == MVN_GEN_AUTO) {
-    // FOLD where it holds the batch (config 2: 15.0 us per step against PIPE's 17.5; at most
-    // 16 sequences), PIPE above that (24); DESIGN.md section 4.1
+    // FOLD where it holds the batch (config 2: 14.6 us per step against PIPE's 16.8; 16 pipelines
+    // of up to 8 sequences), PIPE above that (24 pipelines of up to 8; config 5: 4 of up to 16);
+    // DESIGN.md section 4.1
     if (fold_fits) return MVN_GEN_FOLD;
     if (pipe_fits) return MVN_GEN_PIPE;
     return mvn::stream_ok(dims) ? MVN_GEN_STREAM : MVN_GEN_GENERIC;

@@ -20,6 +20,7 @@
 //
 // Reference arithmetic: see generate.hip (movenet/wavenet.py:217-237,
 // movenet/modules.py:19-30, :67-93, :139-142).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -50,18 +51,27 @@ struct PipeCfg {
   // LDS floats: layer stage LPS*MAT_F + (4 + LPS)*C; head stage: tables or conv1 weights
   // (32768 either way) + a0[C] + a1[Q] + logits[Q]; + 16 flag words
   static constexpr int LDS_FLOATS = 32768 + 8 * CC + 2 * Q + 64 + 16;
+  // Rounds (r3, as in generate_fold.hip): a pipeline serves up to GMAX sequences in turn -- weights
+  // shared, one inbox per sequence and stage; between its turns a sequence's past-tap sums wait in
+  // LDS behind the step vectors, PFS_F floats per channel (16 KB either way)
+  static constexpr int GMAX = CC == 64 ? 8 : 16;
+  static constexpr int PFS_F = 2 * LPS;
+  static constexpr int LDS_FLOATS_MULTI = LDS_FLOATS + GMAX * CC * PFS_F;
 };
 // Workgroup = 8 waves.  Waves 0-3 ("FG group") own the filter/gate matrices, waves
 // 4-7 ("RS group") the residual/skip matrices: at any moment ONE wave per SIMD is
 // issuing, so the dependent chain is not slowed by a co-resident wave replaying the
 // same bookkeeping instructions, and each thread keeps LPS x 2 x KPER weights = 128
 // VGPRs resident.
-template <int CC>
+//
+// MULTI = false: one sequence per pipeline (nseq == nb).  MULTI = true: pipeline b serves sequences
+// b, b + nb, b + 2 nb, ... < nseq in turn, one step of each per round.
+template <int CC, bool MULTI>
 __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, unsigned *err, int NS,
-                                                         int nb) {
+                                                         int nb, int nseq) {
   using P = PipeCfg<CC>;
   constexpr int C = P::C, Q = P::Q, NT = P::NT, LPS = P::LPS, KQ = P::KQ, KPER = P::KPER;
-  constexpr int NF4 = P::NF4, MAT_F = P::MAT_F, GRAN = P::GRAN, GL = P::GL;
+  constexpr int NF4 = P::NF4, MAT_F = P::MAT_F, GRAN = P::GRAN, GL = P::GL, PFS_F = P::PFS_F;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroup i is dispatched to XCD i % 8 (observed; every edge verifies its placement
@@ -86,9 +96,12 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const int L = a.L;
   const int s_next = s + 1 == NS ? 0 : s + 1;
+  const int G = MULTI ? (nseq - b + nb - 1) / nb : 1;  // sequences of this pipeline
+  int bq = b;                                           // the sequence whose turn it is
   u64 *inbox = hand + ((size_t)b * NS + s) * GRAN;
   u64 *outbox = hand + ((size_t)b * NS + s_next) * GRAN;
   int *iflag = (int *)(smem + P::LDS_FLOATS - 16);  // [0] ok flag, [3] fast-edge flag
+  float *pfs = smem + P::LDS_FLOATS;                // MULTI: [GMAX][C][PFS_F] (layer stages), head: indices
   // placement handshake: publish my XCC id (+1), read my consumer's
   bool fast_edge = false;
   {
@@ -124,6 +137,12 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
     float *skin = pastb + LPS * C;     // [C] running skip sum as received
     float *ctxb = skin + C;            // [C] context vector of the step being prepared
     float *ring = a.state + (size_t)b * a.state_per_seq;
+    auto bind = [&](int g) {  // MULTI: the pointers of sequence b + g nb
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      ring = a.state + (size_t)bq * a.state_per_seq;
+    };
 
     v2f wa[LPS][2 * NF4], wb[LPS][2 * NF4];  // FG: f_c | g_c current-tap rows; RS: res_c | skip_c
     float bias_r[LPS], bias_s[LPS], pf[LPS], pg[LPS], xs[LPS];
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           }
       }
       if (a.ctx_tm && fg_group && tq < C)
-        ctxb[tq] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)tn * C + tq];
+        ctxb[tq] = a.ctx_tm[(size_t)bq * a.ctx_stride_b + (size_t)tn * C + tq];
       __syncthreads();
       if (fg_group) {
 #pragma unroll
@@ -197,10 +216,41 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           }
       }
     };
+    // MULTI: a sequence's pf / pg between its turns (only the lead lane of a channel uses them)
+    auto save_pf = [&](int g) {
+      if (MULTI && fg_group && lead) {
+        float *q = pfs + ((size_t)g * C + c) * PFS_F;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) *(v2f *)(q + 2 * j) = v2f{pf[j], pg[j]};
+      }
+    };
+    auto load_pf = [&](int g) {
+      if (MULTI && fg_group && lead) {
+        const float *q = pfs + ((size_t)g * C + c) * PFS_F;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+          const v2f v = *(const v2f *)(q + 2 * j);
+          pf[j] = v.x;
+          pg[j] = v.y;
+        }
+      }
+    };
     __syncthreads();
-    precompute(a.t_begin, false);
+    if (MULTI) {
+      for (int g = 0; g < G; ++g) {
+        bind(g);
+        precompute(a.t_begin, false);
+        save_pf(g);
+        __syncthreads();  // the filter/gate waves have read this sequence's popped entries
+      }
+    } else {
+      precompute(a.t_begin, false);
+    }
 
-    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) bind(g);
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       // The step starts as soon as the C residual-stream granules are in; the running skip sum
       // (sent a little later by the producer, see below) is awaited by wave 4 while the filter/gate
@@ -239,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
       }
       lds_barrier();
       MVN_STAMP(b, s, ts - a.t_begin, 0);
+      load_pf(g);
       if constexpr (SPLIT) {
         if (wave == 4) {  // off the chain: the residual/skip waves idle during the first f/g phase
           float v[2];
@@ -340,14 +391,15 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 5, 0);
         }
       MVN_STAMP(b, s, ts - a.t_begin, 1);
-      if constexpr (SPLIT) {
-        // (iflag[1] was written by wave 4 before the first f/g -> r/s barrier of this step)
-        if (iflag[0] == 0 || iflag[1] == 0) break;
-      } else {
-        if (iflag[0] == 0) break;  // hand-off timed out (checked after the step: off the chain)
+      // hand-off timed out (checked after the step: off the chain; iflag[1] was written by wave 4
+      // before the first f/g -> r/s barrier of this step)
+      if (iflag[0] == 0 || (SPLIT && iflag[1] == 0)) {
+        alive = false;
+        break;
       }
       if (ts + 1 < a.t_end) {
         precompute(ts + 1, true);
+        save_pf(g);
       } else if (!fg_group && lead) {
         // last step of the launch: push only (the next launch pops in its prologue)
 #pragma unroll
@@ -375,6 +427,13 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
     const f4 *W1p = (const f4 *)hw, *W2p = (const f4 *)(hw + P::W1_F + Q);
     const float *b1 = hw + P::W1_F, *b2 = hw + P::W1_F + Q + P::W2_F;
     int32_t *samples = a.samples + (size_t)b * a.stride;
+    int *hidx = (int *)pfs;  // MULTI: [GMAX][2] = {idx_cur, idx_prev} of each sequence between its turns
+    auto bind = [&](int g) {
+      bq = b + g * nb;
+      inbox = hand + ((size_t)bq * NS + s) * GRAN;
+      outbox = hand + ((size_t)bq * NS + s_next) * GRAN;
+      samples = a.samples + (size_t)bq * a.stride;
+    };
 
     // conv1: thread (o1 = tid>>1, q1 = tid&1), C/2 inputs; conv2: thread (og = tid>>3,
     // q2 = tid&7), 4 outputs x 32 inputs
@@ -410,14 +469,31 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
         put_granule(outbox + C + ch, ep, 0.f, fast_edge);
       }
     };
-    if (wave == 0) {
-      idx_cur = samples[a.t_begin];
-      idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
-      if (a.t_begin < a.t_end) send_h0(1u);
-      MVN_STAMP(b, s, 0, 1);
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) bind(g);
+      if (wave == 0) {
+        idx_cur = samples[a.t_begin];
+        idx_prev = a.t_begin > 0 ? samples[a.t_begin - 1] : -1;
+        if (a.t_begin < a.t_end) send_h0(1u);
+        MVN_STAMP(b, s, 0, 1);
+        if (MULTI && lane == 0) {
+          hidx[2 * g] = idx_cur;
+          hidx[2 * g + 1] = idx_prev;
+        }
+      }
     }
+    if (MULTI) __syncthreads();
 
-    for (int ts = a.t_begin; ts < a.t_end; ++ts) {
+    bool alive = true;
+    for (int ts = a.t_begin; ts < a.t_end && alive; ++ts)
+    for (int g = 0; g < G; ++g) {
+      if (MULTI) {
+        bind(g);
+        if (wave == 0) {  // (written by this wave's lane 0 a whole round ago)
+          idx_cur = hidx[2 * g];
+          idx_prev = hidx[2 * g + 1];
+        }
+      }
       const unsigned epoch = (unsigned)(ts - a.t_begin + 1);
       const int u = ts + 1;
       const bool want_out = (a.logits_out || a.choices_out) && u >= a.logits_t0;
@@ -427,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
       // keeps it from being sunk to its use behind the head's barriers)
       float uni = 0.f;
       if (wave == 0 && a.temperature > 0.f) {
-        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b);
+        uni = philox_uniform(a.seed, (uint32_t)u, (uint32_t)bq);
         asm volatile("" : "+v"(uni));
       }
       if (wave == 0) {
@@ -485,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           float lg[4] = {lv.x, lv.y, lv.z, lv.w};
           if (a.logits_out && u >= a.logits_t0)
             ((f4 *)(a.logits_out +
-                    ((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
+                    ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
           const int pick = choose_class(lg, a.temperature, uni, lane, Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
@@ -493,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           if (ts + 1 < a.t_end) send_h0(epoch + 1);
           MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
           if (lane == 0) {
-            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)b * a.n_total + u] = pick;
+            if (a.choices_out && u >= a.logits_t0) a.choices_out[(size_t)bq * a.n_total + u] = pick;
             if (u >= a.n_given) samples[u] = pick;
           }
         } else {
@@ -502,8 +578,15 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           if (ts + 1 < a.t_end) send_h0(epoch + 1);
           MVN_STAMP(b, s, ts + 1 - a.t_begin, 1);
         }
+        if (MULTI && lane == 0) {
+          hidx[2 * g] = idx_cur;
+          hidx[2 * g + 1] = idx_prev;
+        }
       }
-      if (iflag[0] == 0) break;  // hand-off timed out
+      if (iflag[0] == 0) {  // hand-off timed out
+        alive = false;
+        break;
+      }
     }
   }
 }
@@ -589,11 +672,14 @@ bool pipe_ok(const mvn_dims *d) {
 }
 static int pipe_lps(const mvn_dims *d) { return d->residual_channels == 64 ? 4 : 1; }
 int pipe_stages(const mvn_dims *d) { return (n_layers(d) + pipe_lps(d) - 1) / pipe_lps(d) + 1; }
-int pipe_max_batch(const mvn_dims *d) {
+int pipe_pipelines(const mvn_dims *d) {
   // the kernel's placement: NS <= 32 -> floor(32/NS) pipelines in each of the 8 XCDs,
   // otherwise one pipeline per group of ceil(NS/32) XCDs
   const int NS = pipe_stages(d);
   return NS <= PIPE_XCD_CUS ? 8 * (PIPE_XCD_CUS / NS) : 8 / ((NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS);
+}
+int pipe_max_batch(const mvn_dims *d) {  // each pipeline serves up to GMAX sequences in turn
+  return (d->residual_channels == 64 ? PipeCfg<64>::GMAX : PipeCfg<128>::GMAX) * pipe_pipelines(d);
 }
 size_t pipe_hand_floats(const mvn_dims *d, int batch) {
   // batch * NS inboxes of 2C granules (2 floats each), then 16 flag words (error word
@@ -652,13 +738,16 @@ static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *
                          size_t status_off, hipStream_t s) {
   using P = PipeCfg<CC>;
   int NS = pipe_stages(d);
-  const void *fn = (const void *)gen_pipe_kernel<CC>;
+  // up to pipe_pipelines(d) sequences: one per pipeline; more: ceil(batch / pipelines) each, in turn
+  const int pipes = std::min(batch, pipe_pipelines(d));
+  const bool multi = batch > pipes;
+  const void *fn = multi ? (const void *)gen_pipe_kernel<CC, true> : (const void *)gen_pipe_kernel<CC, false>;
   int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_pipe)");
   if (rc) return rc;
-  const size_t lds_bytes = P::LDS_FLOATS * sizeof(float);
+  const size_t lds_bytes = (multi ? P::LDS_FLOATS_MULTI : P::LDS_FLOATS) * sizeof(float);
   // grid: 8 workgroups (one per XCD) per slot; see the kernel's (xcd, slot) -> (b, s) map
   const int XS = (NS + PIPE_XCD_CUS - 1) / PIPE_XCD_CUS;
-  const int slots = NS <= PIPE_XCD_CUS ? (batch + 7) / 8 * NS : (NS + XS - 1) / XS;
+  const int slots = NS <= PIPE_XCD_CUS ? (pipes + 7) / 8 * NS : (NS + XS - 1) / XS;
   int dev = 0, cus = 0, per_cu = 0, coop = 0;
   if (check_hip(hipGetDevice(&dev), "hipGetDevice") ||
       check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev),
@@ -689,16 +778,13 @@ static int pipe_launch_t(const GenArgs &a, const mvn_dims *d, int batch, float *
   if (rc) return rc;
   u64 *gran = (u64 *)hand;
   GenArgs args = a;
-  int nb = batch;
-  if (coop && pipe_cooperative_launch()) {
-    void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb};
+  int nb = pipes, nseq = batch;
+  void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb, (void *)&nseq};
+  if (coop && pipe_cooperative_launch())
     return check_hip(hipLaunchCooperativeKernel(fn, dim3(slots * 8), dim3(P::NT), kargs,
                                                 (unsigned)lds_bytes, s),
                      "mvn_generate(pipe, cooperative launch)");
-  }
-  hipLaunchKernelGGL(gen_pipe_kernel<CC>, dim3(slots * 8), dim3(P::NT), lds_bytes, s, args, gran, err,
-                     NS, nb);
-  return check_hip(hipGetLastError(), "mvn_generate(pipe)");
+  return check_hip(hipLaunchKernel(fn, dim3(slots * 8), dim3(P::NT), kargs, lds_bytes, s), "mvn_generate(pipe)");
 }
 
 int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, size_t hand_total, size_t status_off,
@@ -710,8 +796,9 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
                 "hipDeviceGetAttribute"))
     return MVN_ERR_LAUNCH;
   if (cus < 8 * PIPE_XCD_CUS || batch > pipe_max_batch(d)) {
-    set_error("PIPE variant: %d stages per sequence, at most %d sequences co-resident on %d CUs "
-              "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_max_batch(d), cus, batch);
+    set_error("PIPE variant: %d stages per pipeline, %d pipelines of at most %d sequences each on %d CUs "
+              "(batch %d asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : pipe_pipelines(d),
+              pipe_max_batch(d) / std::max(1, pipe_pipelines(d)), cus, batch);
     return MVN_ERR_UNSUPPORTED;
   }
   return d->residual_channels == 64 ? pipe_launch_t<64>(a, d, batch, hand, hand_total, status_off, s)

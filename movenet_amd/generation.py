@@ -298,14 +298,16 @@ class RingGenerator:
         return choices, logits
 
 
-# measured microseconds per generated sample-step of ONE launch; keys:
-# (C, variant).  PIPE: any number of co-resident sequences up to the variant's limit.  FOLD: its
-# 16 pipelines (config 2) serve ceil(n / 16) sequences each in turn (r3): 14.7 us for one round,
-# ~15.4 up to five, then the stages' service time per turn (~2.64 us) bounds the step
-# (96: 15.9 us, 112: 18.5, 128: 21.1).
-_T_STEP_US = {(64, N.GEN_FOLD): 15.0, (64, N.GEN_PIPE): 17.5, (128, N.GEN_PIPE): 79.0}
-_FOLD_ROUNDS = 8          # fold::GMAX of csrc/generate_fold.hip
-_FOLD_TURN_US = 2.64
+# Measured cost model of a pipelined launch (DESIGN.md sections 4.1, 4.1c): its P pipelines serve
+# ceil(n / P) sequences each in turn, and a step of ALL of them takes the pipeline's latency as long
+# as the rounds fit under it, then rounds x the stages' service time per turn.  Keys: (C, variant);
+# values: (us per step with one sequence per pipeline, us per step with several while the latency
+# still bounds it, us per turn, most sequences per pipeline = GMAX of the kernel).
+#   FOLD, config 2:  16 pipelines: 14.7 us for 16, 15.3 for 64, 21.1 for 128
+#   PIPE, config 2:  24 pipelines: 17.4 us for 24 .. 96, 25.8 for 144, 34.4 for 192
+#   PIPE, config 5:   4 pipelines: 72.4 us for 4, 73.2 for 5 .. 64 (the turn never bounds it)
+_PIPELINED_US = {(64, N.GEN_FOLD): (14.7, 15.3, 2.64, 8), (64, N.GEN_PIPE): (17.4, 17.6, 4.3, 8),
+                 (128, N.GEN_PIPE): (72.4, 73.2, 4.5, 16)}
 # ... and of the best kernel that takes EVERY sequence in one launch; keys: (C, conditioned):
 # STREAM at C=64 without conditioning, GENERIC otherwise
 _T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128, True): 490.0}
@@ -313,15 +315,13 @@ _T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128,
 
 def _launch_step_us(dims, variant: int, n: int):
     """Modelled step time (us) of ONE launch of ``variant`` holding ``n`` sequences, or None."""
-    C = dims.residual_channels
-    t = _T_STEP_US.get((C, variant))
-    if t is None:
+    model = _PIPELINED_US.get((dims.residual_channels, variant))
+    if model is None:
         return None
-    if variant == N.GEN_FOLD:
-        pipes = max(1, max_pipe_batch(dims, variant) // _FOLD_ROUNDS)
-        rounds = -(-n // pipes)
-        return t if rounds <= 1 else max(t + 0.5, _FOLD_TURN_US * rounds)
-    return t
+    t_one, t_multi, t_turn, gmax = model
+    pipes = max(1, max_pipe_batch(dims, variant) // gmax)
+    rounds = -(-n // pipes)
+    return t_one if rounds <= 1 else max(t_multi, t_turn * rounds)
 
 
 def auto_plan(dims, batch: int, has_context: bool):
@@ -329,29 +329,33 @@ def auto_plan(dims, batch: int, has_context: bool):
     ``("single", 0, variant)`` for one launch or ``("grouped", group, variant)`` for groups of
     ``group`` sequences taking turns on the pipelines of a pipelined variant.
 
-    Chosen on measured per-step cost.  C=K=64: ONE FOLD launch holds up to 128 sequences (16
-    pipelines x 8 rounds: 14.7 us for 16, 15.4 for 64, 21.1 for 128); beyond that balanced groups
-    of FOLD launches take turns as long as they beat the one-launch kernels (STREAM 78 us /
-    conditioned GENERIC ~0.3 ms for any number).  C=K=128: PIPE 79 us for up to 4, groups of 4
-    up to 24, GENERIC 490 us beyond."""
+    Chosen on measured per-step cost (the table above).  C=K=64: ONE FOLD launch up to 128 sequences
+    (16 pipelines x 8 rounds), one PIPE launch where its 24 pipelines need fewer rounds (129 .. ~160),
+    then balanced groups of FOLD launches as long as they beat the one-launch kernels (STREAM 78 us /
+    conditioned GENERIC ~0.3 ms for any number).  C=K=128: ONE PIPE launch up to 64 sequences (4
+    pipelines x 16 rounds, 73 us whatever the number), groups of up to 64 until GENERIC's 490 us is
+    cheaper (beyond 384)."""
     lib = N.lib()
     single = N.check(lib.mvn_gen_variant(dims, N.GEN_AUTO, batch), "mvn_gen_variant")
-    if single in N.PIPE_VARIANTS:
-        return "single", 0, single
     C = dims.residual_channels
     best = None
     for variant in (N.GEN_FOLD, N.GEN_PIPE):
         cap = max_pipe_batch(dims, variant)
-        if cap <= 0 or _T_STEP_US.get((C, variant)) is None:
+        if cap <= 0 or (C, variant) not in _PIPELINED_US:
             continue
         k = -(-batch // cap)          # launches per step
         group = -(-batch // k)        # balanced: the step time of a launch grows with its rounds
         cost = k * _launch_step_us(dims, variant, group)
         if best is None or cost < best[0]:
-            best = (cost, group, variant)
-    if best is not None and best[0] < _T_SINGLE_US.get((C, bool(has_context)), 0.0):
-        return "grouped", best[1], best[2]
-    return "single", 0, single
+            best = (cost, k, group, variant)
+    if best is None:
+        return "single", 0, single
+    cost, k, group, variant = best
+    if k == 1:
+        return "single", 0, variant
+    if cost < _T_SINGLE_US.get((C, bool(has_context)), 0.0):
+        return "grouped", group, variant
+    return "single", 0, single  # the kernel the C library's AUTO names: every sequence in one launch
 
 
 def max_pipe_batch(dims, variant: int = N.GEN_PIPE) -> int:

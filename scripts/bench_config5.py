@@ -20,7 +20,7 @@ rf, n_new = 6144, 22050
 flop_per_sample = 2 * (60 * (5 * 128 * 128 + 128 * 128) + 128 * 256 + 256 * 256)  # 11,993,088
 out = {}
 FP16_ONLY = "--fp16-only" in sys.argv
-for name, variant, batches in (("fp32 (gen_pipe_kernel<128>, 61 stages)", N.GEN_PIPE, (1, 4)),
+for name, variant, batches in (("fp32 (gen_pipe_kernel<128>, 61 stages; beyond 4 sequences the 4 pipelines serve them in turn)", N.GEN_PIPE, (1, 4, 16, 64)),
                                ("fp16 operands / fp32 accumulate (gen_pipe_h16_kernel, 21 stages; 31 beyond 8 sequences)", N.GEN_PIPE_F16, (1, 4, 8, 16, 64)),
                                ("fp32 generic kernel", N.GEN_GENERIC, (1,))):
     for B in batches:

@@ -48,15 +48,19 @@ def test_generate_sizes_and_variants():
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_FOLD
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 17) == N.GEN_FOLD
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 128) == N.GEN_FOLD
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 129) == N.GEN_STREAM
-    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 64) == N.MVN_ERR_UNSUPPORTED
-    # PIPE: one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 129) == N.GEN_PIPE   # 24 pipelines x 8 rounds
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 192) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 193) == N.GEN_STREAM
+    # PIPE: one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all, each
+    # serving up to 8 sequences in turn (r3)
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 24) == N.GEN_PIPE
-    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 25) == N.MVN_ERR_UNSUPPORTED
-    # BASELINE config 5 (60 layers, C=K=128): 61 stages span 2 XCDs -> 4 sequences
+    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 192) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 193) == N.MVN_ERR_UNSUPPORTED
+    # BASELINE config 5 (60 layers, C=K=128): 61 stages span 2 XCDs -> 4 pipelines of up to 16 sequences
     d5 = N.make_dims(10, 6, 256, 128, 128)
     assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 4) == N.GEN_PIPE
-    assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 5) == N.GEN_GENERIC
+    assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 64) == N.GEN_PIPE
+    assert lib.mvn_gen_variant(d5, N.GEN_AUTO, 65) == N.GEN_GENERIC
     n5 = 2 * 256 * 128 + 60 * (6 * 128 * 128 + 2 * 128) + 256 * 128 + 256 + 256 * 256 + 256
     assert lib.mvn_gen_weights_floats(d5, N.GEN_PIPE) == n5 + 60 * (2 * 128 * 128 + 256)
     assert lib.mvn_gen_weights_floats(d5, N.GEN_GENERIC) == n5 + 60 * (2 * 128 * 128 + 256)

@@ -202,7 +202,7 @@ def test_fp16_capacity_one_xcd():
     eight sequences each (fp32: 61 stages over two XCDs, four sequences)."""
     from movenet_amd.generation import max_pipe_batch
     d5 = N.make_dims(10, 6, 256, 128, 128)
-    assert max_pipe_batch(d5, N.GEN_PIPE) == 4 and max_pipe_batch(d5, N.GEN_PIPE_F16) == 64
+    assert max_pipe_batch(d5, N.GEN_PIPE) == 64 and max_pipe_batch(d5, N.GEN_PIPE_F16) == 64
     assert N.lib().mvn_gen_variant(d5, N.GEN_AUTO, 1) == N.GEN_PIPE  # fp32 stays the default
 
 

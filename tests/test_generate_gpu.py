@@ -211,13 +211,14 @@ def test_config2_pipe_at_full_occupancy():
         g.check_errors()
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
-    assert _gen(cfg, sd, 129, rf + 1).variant == N.GEN_STREAM  # AUTO falls back
+    assert _gen(cfg, sd, 129, rf + 1).variant == N.GEN_PIPE    # AUTO at the C level: 24 pipelines x 8 rounds
+    assert _gen(cfg, sd, 193, rf + 1).variant == N.GEN_STREAM  # ... and falls back beyond
     assert _gen(cfg, sd, 24, rf + 1).variant == N.GEN_FOLD     # AUTO: FOLD wherever it holds the batch
     assert _gen(cfg, sd, 128, rf + 1, variant=N.GEN_FOLD).variant == N.GEN_FOLD  # 16 pipelines x 8 rounds
     with pytest.raises(Exception):
         _gen(cfg, sd, 129, rf + 1, variant=N.GEN_FOLD)
     with pytest.raises(Exception):
-        _gen(cfg, sd, 25, rf + 1, variant=N.GEN_PIPE)
+        _gen(cfg, sd, 193, rf + 1, variant=N.GEN_PIPE)  # 24 pipelines x 8 rounds
 
 
 def test_grouped_pipelines_beyond_one_launch():
@@ -229,7 +230,7 @@ def test_grouped_pipelines_beyond_one_launch():
     cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
     sd = make_state_dict(**cfg, seed=6, gain=2.0, head_gain=6.0)
     rf, B, n_new = 3072, 40, 24
-    assert max_pipe_batch(N.make_dims(10, 3, 256, 64, 64)) == 24
+    assert max_pipe_batch(N.make_dims(10, 3, 256, 64, 64)) == 192  # 24 pipelines x 8 rounds
     pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
     ref = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_STREAM)
     ref.prime(pidx)
@@ -284,6 +285,63 @@ def test_fold_pipelines_serve_several_sequences_in_turn(B):
         picks[variant], logits[variant] = choices[:, rf:].cpu().numpy(), lg.cpu().numpy()
     assert rel_err(logits[N.GEN_FOLD], logits[N.GEN_STREAM]) < LOGIT_TOL
     assert (picks[N.GEN_FOLD] == picks[N.GEN_STREAM]).mean() >= 0.999
+
+
+@pytest.mark.parametrize("shape,B,n_new", [("c64", 40, 24), ("c128", 22, 600), ("c128", 64, 30)])
+def test_pipe_pipelines_serve_several_sequences_in_turn(shape, B, n_new):
+    """r3: the fp32 PIPE kernel serves several sequences per pipeline too (gen_pipe_kernel<C, true>: 24
+    nine-stage pipelines of up to 8 sequences at C = 64, 4 sixty-one-stage pipelines of up to 16 at
+    C = K = 128 -- config 5's batch of 16 in ONE launch).  A sequence's arithmetic is the same whatever
+    its pipeline's round count, so teacher-forced logits are BIT-equal to launches that hold one sequence
+    per pipeline; greedy runs equal the one-launch kernels' (STREAM / GENERIC), chunked launches equal
+    one launch (the long run crosses the 512-step queue wrap), and sampled draws (Philox counter: seed,
+    step, SEQUENCE) equal the one-launch kernel's on >= 99.5 % of the draws."""
+    from movenet_amd.generation import max_pipe_batch
+    from movenet_amd.utils.weights import make_state_dict
+    if shape == "c64":
+        cfg, other, per_launch = dict(CFG2), N.GEN_STREAM, 24
+    else:
+        cfg = dict(layer_size=10, stack_size=6, input_channels=256, residual_channels=128, skip_channels=128)
+        other, per_launch = N.GEN_GENERIC, 4
+    sd = make_state_dict(**cfg, seed=6, gain=2.0 if shape == "c64" else 1.5, head_gain=6.0)
+    dims = O.Dims(**cfg)
+    rf = dims.receptive_fields
+    assert max_pipe_batch(N.make_dims(cfg["layer_size"], cfg["stack_size"], 256, cfg["residual_channels"],
+                                      cfg["skip_channels"])) == (192 if shape == "c64" else 64)
+    pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
+    ref = _gen(cfg, sd, B, rf + n_new, variant=other)
+    ref.prime(pidx)
+    ref.advance(n_new)
+    g = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_PIPE)
+    assert g.variant == N.GEN_PIPE
+    g.prime(pidx)
+    g.advance(n_new)
+    g.check_errors()
+    assert torch.equal(g.samples, ref.samples)
+    assert len(torch.unique(g.samples[:, rf:])) > 4
+    g2 = _gen(cfg, sd, B, rf + n_new, variant=N.GEN_PIPE)
+    g2.prime(pidx)
+    g2.advance(10)
+    g2.advance(n_new - 10)
+    g2.check_errors()
+    assert torch.equal(g2.samples, ref.samples)
+    hist = synthetic_indices(B, rf + 24, 256, 4321).to(DEV)
+    picks, logits = {}, {}
+    for variant in (other, N.GEN_PIPE):
+        gt = _gen(cfg, sd, B, rf + 24, variant=variant, temperature=1.0, seed=77)
+        choices, lg = gt.teacher_forced(hist, logits_t0=rf)
+        gt.check_errors()
+        picks[variant], logits[variant] = choices[:, rf:].cpu().numpy(), lg.cpu()
+    assert rel_err(logits[N.GEN_PIPE].numpy(), logits[other].numpy()) < LOGIT_TOL
+    # (a draw differs only where the uniform falls within the two kernels' rounding distance of a step
+    # of the CDF: ~1e-3 of the draws at C = 128; a wrong Philox counter would change nearly all of them)
+    assert (picks[N.GEN_PIPE] == picks[other]).mean() >= 0.995
+    for lo in range(0, B, per_launch):  # one sequence per pipeline: the same arithmetic, bit for bit
+        hi = min(B, lo + per_launch)
+        gs = _gen(cfg, sd, hi - lo, rf + 24, variant=N.GEN_PIPE)
+        _, lg = gs.teacher_forced(hist[lo:hi].contiguous(), logits_t0=rf)
+        gs.check_errors()
+        assert torch.equal(lg.cpu(), logits[N.GEN_PIPE][lo:hi]), (lo, hi)
 
 
 def test_bad_input_raises():
@@ -529,14 +587,18 @@ def test_auto_plan_cost_based():
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
     for n in (1, 16, 20, 32, 64, 128):                                 # one FOLD launch, 1 - 8 rounds
         assert auto_plan(d2, n, False) == ("single", 0, N.GEN_FOLD)
-    assert auto_plan(d2, 129, False) == ("grouped", 65, N.GEN_FOLD)   # 2 x 5 rounds: 31 us < 78 us
+    assert auto_plan(d2, 129, False) == ("single", 0, N.GEN_PIPE)     # 24 pipelines x 6 rounds: 25.8 us < 2 x 15.3
+    assert auto_plan(d2, 144, True) == ("single", 0, N.GEN_PIPE)
+    assert auto_plan(d2, 192, False) == ("grouped", 96, N.GEN_FOLD)   # 2 x 15.8 us < 34.4 (PIPE, 8 rounds)
     assert auto_plan(d2, 256, False) == ("grouped", 128, N.GEN_FOLD)  # 2 x 21.1 us
     assert auto_plan(d2, 400, False) == ("grouped", 100, N.GEN_FOLD)  # 4 x 18.5 us
     assert auto_plan(d2, 500, False) == ("single", 0, N.GEN_STREAM)   # 4 x 21.1 us > 78 us
     assert auto_plan(d2, 500, True) == ("grouped", 125, N.GEN_FOLD)   # no conditioned STREAM kernel
-    assert auto_plan(d5, 4, False) == ("single", 0, N.GEN_PIPE)
-    assert auto_plan(d5, 24, False) == ("grouped", 4, N.GEN_PIPE)
-    assert auto_plan(d5, 25, False) == ("single", 0, N.GEN_GENERIC)
+    for n in (1, 4, 5, 16, 24, 64):                                    # one PIPE launch, 1 - 16 rounds: 73 us
+        assert auto_plan(d5, n, False) == ("single", 0, N.GEN_PIPE)
+    assert auto_plan(d5, 65, False) == ("grouped", 33, N.GEN_PIPE)    # 2 x 73 us < 490 us
+    assert auto_plan(d5, 384, False) == ("grouped", 64, N.GEN_PIPE)   # 6 x 73 us
+    assert auto_plan(d5, 385, False) == ("single", 0, N.GEN_GENERIC)  # 7 x 73 us > 490 us
 
 
 @pytest.mark.parametrize("layer_size,stack_size", [(1, 1), (2, 1), (4, 1), (5, 2), (10, 2), (7, 3)])
