@@ -97,9 +97,12 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
 #define MVN_GEN_GENERIC 1
 #define MVN_GEN_STREAM 2
 #define MVN_GEN_PIPE 3 /* C=K in {64,128}, Q=256: layer pipeline over ceil(L/4)+1 (C=64)
-                          or L+1 (C=128) CUs per sequence, weights resident in
-                          registers/LDS, activations handed on as 8-byte granules;
-                          needs all stages co-resident, at most 32 per XCD         */
+                          or L+1 (C=128) CUs, weights resident in registers/LDS,
+                          activations handed on as 8-byte granules; needs all stages
+                          co-resident, at most 32 per XCD: 24 pipelines at config 2, 4 at
+                          config 5 (61 stages, two XCDs each); a pipeline serves up to 8
+                          (C=64) / 16 (C=128) sequences in turn within one launch: 192 /
+                          64 sequences.  Config 5: 73 us per step for 1 .. 64 sequences.   */
 
 #define MVN_GEN_PIPE_F16 4 /* C=K=128, Q=256: the PIPE structure with FP16 OPERANDS and FP32
                               ACCUMULATION (BASELINE configs[4]; precedent: torch.autocast,
