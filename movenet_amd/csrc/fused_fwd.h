@@ -35,6 +35,7 @@ struct FusedFwdPArgs {
   // conditioned layers (strip kernel only): f,g += Wc ctx(t) + bc   (modules.py:58-63, :75-77)
   const float *wcf = nullptr, *wcg = nullptr, *bcf = nullptr, *bcg = nullptr;  // (64, 64), (64)
   Act ctx = Act{nullptr, 0, 0};
+  const float *wpack = nullptr;  // fused_fwd_bf3.h: the layer's LDS image, written once per forward call (or NULL)
 };
 
 // NTB = 32-step blocks per tile: 2 -> 64-column tiles, 512 threads, one workgroup per CU (122 KB of

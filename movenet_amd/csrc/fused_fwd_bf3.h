@@ -1,0 +1,468 @@
+// fp32 products on the bf16 matrix cores: the strip forward of an audio-only layer, form "bf16 x 3".
+//
+// CDNA4's fp32 MFMA (v_mfma_f32_32x32x2_f32: 64 cycles for 4096 FLOP) is 1/16 of its bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16: <= 32 cycles for 32768 FLOP), and an fp32 MFMA holds the SIMD's vector
+// lanes while it runs (scripts/probes/mfma_valu_overlap.hip) where a bf16 MFMA leaves 24 of its 32
+// cycles to other instructions.  An fp32 number is EXACTLY the sum of three bf16 numbers
+//     x = h + m + l,   h = top16(x),  m = top16(x - h),  l = top16(x - h - m)      (8 + 8 + 8 mantissa bits;
+// the two subtractions are exact), so a product of two fp32 numbers is the sum of nine bf16 products, each
+// exact in the fp32 accumulator; the six of them with weight >= 2^-16 (hh, hm, mh, mm, hl, lh) carry
+// everything above 2^-24 of the product -- what an fp32 multiply keeps.  Six bf16 MFMAs replace the eight fp32
+// MFMAs of a 32 x 32 x 16 block: 2.7 - 5 x less matrix time (scripts/probes/mfma_bf16_split.hip: 2048 -> 470
+// cycles per block and SIMD, the split of the B operand included), with fp32's exponent range (no scaling,
+// no overflow: bf16 has fp32's exponent) and fp32-class error (numpy model in DESIGN 4.2b: max error of a
+// 256-term product 4.7e-7 of the output range against 5.7e-7 for fp32 sums in numpy's order).
+//
+// Same structure as fused_layer64s_kernel<false> (fused_fwd.h): one wave owns a strip of 32 columns, no
+// barrier, the strip's input goes from global memory into registers in ACCUMULATOR order and is the B operand;
+// gate in registers; z in accumulator order is the second product's B operand.  What changes:
+//   * weights in LDS as three bf16 planes, [block][k-step of 16][plane][lane][8 bf16]: one ds_read_b128 per
+//     plane feeds an MFMA's A operand (lane -> output row, lane half -> which 8 of the step's 16 inputs); 144 KB;
+//   * a k-step takes 8 consecutive input registers of the lane (8 channels of its lane half), split into three
+//     packed planes (22 vector instructions) that all four row blocks share: 6 MFMAs each;
+//   * per strip 288 bf16 MFMAs instead of 384 fp32 ones, 144 ds_read_b128 instead of 96.
+#pragma once
+
+namespace mvn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf3_top(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// three bf16 planes of 8 fp32 values, element e of a plane = value e (two per register, low half first)
+__device__ __forceinline__ void bf3_split8(const float *x, u32x4 &h, u32x4 &m, u32x4 &l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const unsigned ah = bf3_top(a), bh = bf3_top(b);
+    const float ar = a - __uint_as_float(ah), br = b - __uint_as_float(bh);   // exact
+    const unsigned am = bf3_top(ar), bm = bf3_top(br);
+    const float ar2 = ar - __uint_as_float(am), br2 = br - __uint_as_float(bm);  // exact
+    h[i] = __builtin_amdgcn_perm(bh, ah, 0x07060302);  // {top16(b), top16(a)}
+    m[i] = __builtin_amdgcn_perm(bm, am, 0x07060302);
+    l[i] = __builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302);
+  }
+}
+
+// two values into register i of the three planes (a quarter of bf3_split8: the pipelined products below split
+// the NEXT k-step's operand a pair at a time between the MFMAs of the current one)
+__device__ __forceinline__ void bf3_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  const unsigned ah = bf3_top(a), bh = bf3_top(b);
+  const float ar = a - __uint_as_float(ah), br = b - __uint_as_float(bh);
+  const unsigned am = bf3_top(ar), bm = bf3_top(br);
+  const float ar2 = ar - __uint_as_float(am), br2 = br - __uint_as_float(bm);
+  h = __builtin_amdgcn_perm(bh, ah, 0x07060302);
+  m = __builtin_amdgcn_perm(bm, am, 0x07060302);
+  l = __builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302);
+}
+
+// one value into its three 16-bit planes (weight staging)
+__device__ __forceinline__ void bf3_split1(float w, unsigned short &h, unsigned short &m, unsigned short &l) {
+  const unsigned wh = bf3_top(w);
+  const float r = w - __uint_as_float(wh);
+  const unsigned wm = bf3_top(r);
+  const float r2 = r - __uint_as_float(wm);
+  h = (unsigned short)(wh >> 16);
+  m = (unsigned short)(wm >> 16);
+  l = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// acc += A (three planes at LDS byte address `wa`, 1 KB apart) x B (three planes): smallest terms first
+__device__ __forceinline__ void bf3_mfma6(f32x16 &acc, unsigned wa, const u32x4 &bh, const u32x4 &bm, const u32x4 &bl) {
+  typedef __attribute__((address_space(3))) u32x4 lds_u4;
+  const u32x4 ah = *(const lds_u4 *)(uintptr_t)wa;
+  const u32x4 am = *(const lds_u4 *)(uintptr_t)(wa + 1024u);
+  const u32x4 al = *(const lds_u4 *)(uintptr_t)(wa + 2048u);
+#if MVN_EXP == 25
+#define BF3_MF(a_, b_) acc[0] += __uint_as_float(a_[0] ^ b_[0])
+#else
+#define BF3_MF(a_, b_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc, 0, 0, 0)
+#endif
+  BF3_MF(al, bh);
+  BF3_MF(ah, bl);
+  BF3_MF(am, bm);
+  BF3_MF(am, bh);
+  BF3_MF(ah, bm);
+  BF3_MF(ah, bh);
+#undef BF3_MF
+}
+
+// acc[0..3] += W (4 row blocks, NKS k-steps, three planes each in LDS) x B, software-pipelined: step (ks, blk)
+// requests the NEXT step's three A planes first, then issues its six MFMAs with a pair of the next k-step's B
+// values split between them -- a ds_read has six MFMAs (>= 192 cycles) to arrive, the 88 vector instructions of a
+// split are spread over the 24 MFMAs of a k-step, which leave 24 of their 32 cycles to them.  The scheduling
+// groups pin that order (the compiler's own put each read right in front of its MFMA: 44 % of the wave cycles
+// were waits on LDS, SQ_WAIT_ANY of the build without global accesses).
+//   BVAL: expression of (ks_, e_) = value e_ of k-step ks_'s eight
+#ifndef MVN_BF3_PIPELINED
+#define MVN_BF3_PIPELINED (MVN_EXP != 27)  // (timing build 27: the products as plain loops, right results: 98 us per layer against 89)
+#endif
+#define BF3_PRODUCT(NKS, WA, WB, BVAL)                                                                              \
+  {                                                                                                                 \
+    typedef __attribute__((address_space(3))) u32x4 lds_u4_;                                                        \
+    u32x4 A_[2][3], B_[2][3];                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+      const int ks_ = 0;                                                                                            \
+      float p0_, p1_;                                                                                               \
+      { const int e_ = 2 * i_; p0_ = (BVAL); }                                                                      \
+      { const int e_ = 2 * i_ + 1; p1_ = (BVAL); }                                                                  \
+      unsigned h_, m_, l_;                                                                                          \
+      bf3_split2(p0_, p1_, h_, m_, l_);                                                                             \
+      B_[0][0][i_] = h_; B_[0][1][i_] = m_; B_[0][2][i_] = l_;                                                      \
+    }                                                                                                               \
+    _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) A_[0][pl_] = *(const lds_u4_ *)(uintptr_t)((WA) + 1024u * pl_); \
+    _Pragma("unroll") for (int ksx_ = 0; ksx_ < (NKS); ++ksx_) {                                                    \
+      _Pragma("unroll") for (int blk_ = 0; blk_ < 4; ++blk_) {                                                      \
+        const int s_ = ksx_ * 4 + blk_;                                                                             \
+        if (s_ + 1 < 4 * (NKS)) {                                                                                   \
+          const int nk_ = (s_ + 1) >> 2, nb_ = (s_ + 1) & 3;                                                        \
+          const unsigned ad_ = (nb_ < 2 ? (WA) : (WB)) + 3072u * (unsigned)((nb_ & 1) * (NKS) + nk_);               \
+          _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_)                                                       \
+            A_[(s_ + 1) & 1][pl_] = *(const lds_u4_ *)(uintptr_t)(ad_ + 1024u * pl_);                               \
+        }                                                                                                           \
+        if (ksx_ + 1 < (NKS)) {                                                                                     \
+          const int ks_ = ksx_ + 1;                                                                                 \
+          float p0_, p1_;                                                                                           \
+          { const int e_ = 2 * blk_; p0_ = (BVAL); }                                                                \
+          { const int e_ = 2 * blk_ + 1; p1_ = (BVAL); }                                                            \
+          unsigned h_, m_, l_;                                                                                      \
+          bf3_split2(p0_, p1_, h_, m_, l_);                                                                         \
+          B_[(ksx_ + 1) & 1][0][blk_] = h_; B_[(ksx_ + 1) & 1][1][blk_] = m_; B_[(ksx_ + 1) & 1][2][blk_] = l_;     \
+        }                                                                                                           \
+        const u32x4 ah_ = A_[s_ & 1][0], am_ = A_[s_ & 1][1], al_ = A_[s_ & 1][2];                                  \
+        const u32x4 bh_ = B_[ksx_ & 1][0], bm_ = B_[ksx_ & 1][1], bl_ = B_[ksx_ & 1][2];                            \
+        BF3_MF1(acc[blk_], al_, bh_);                                                                               \
+        BF3_MF1(acc[blk_], ah_, bl_);                                                                               \
+        BF3_MF1(acc[blk_], am_, bm_);                                                                               \
+        BF3_MF1(acc[blk_], am_, bh_);                                                                               \
+        BF3_MF1(acc[blk_], ah_, bm_);                                                                               \
+        BF3_MF1(acc[blk_], ah_, bh_);                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                                          \
+        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                          \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                        \
+        }                                                                                                           \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+#if MVN_EXP == 25
+#define BF3_MF1(c_, a_, b_) c_[0] += __uint_as_float(a_[0] ^ b_[0])
+#else
+#define BF3_MF1(c_, a_, b_) \
+  c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
+#endif
+
+constexpr int FS3_W1_BYTES = 4 * 8 * 3 * 1024, FS3_W2_BYTES = 4 * 4 * 3 * 1024;  // 96 KB + 48 KB
+constexpr int FS3_LDS_BYTES = FS3_W1_BYTES + FS3_W2_BYTES + 128 * 4;
+
+// The layer's weights as the kernel's LDS image: W1 [4 blocks][8 k-steps][3 planes][64 lanes][8 bf16], W2 [4][4][3][64][8],
+// then br | bs as floats.  Input register j of a lane of half lh holds channel (j & 3) + 8 (j >> 2) + 4 lh; k-step ks
+// takes registers 8 ks' .. 8 ks' + 7: ks 0..3 of x(t) (tap 1), ks 4..7 of x(t - d) (tap 0).  `img` may be LDS or global.
+template <class Ptr>
+__device__ __forceinline__ void fs3_stage_weights(Ptr img, const float *wf, const float *wg, const float *wr,
+                                                  const float *ws, const float *br, const float *bs, int tid, int nthreads) {
+  unsigned short *W1 = (unsigned short *)img;
+  unsigned short *W2 = (unsigned short *)(img + FS3_W1_BYTES);
+  float *BI = (float *)(img + FS3_W1_BYTES + FS3_W2_BYTES);
+  for (int sI = tid; sI < 2 * 8192; sI += nthreads) {
+    const int g = sI >> 13, r = sI & 8191;        // g: 0 filter, 1 gate; source (out, in, tap)
+    const int tap = r & 1, kc = (r >> 1) & 63, cm = r >> 7;
+    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3);
+    const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs, ks = (tap ? 0 : 4) + (j >> 3);
+    unsigned short h, m, l;
+    bf3_split1((g ? wg : wf)[r], h, m, l);
+    const int at = (((blk * 8 + ks) * 3) * 64 + ln) * 8 + (j & 7);
+    W1[at] = h;
+    W1[at + 512] = m;
+    W1[at + 1024] = l;
+  }
+  for (int sI = tid; sI < 2 * 4096; sI += nthreads) {
+    const int g = sI >> 12, r = sI & 4095;        // g: 0 residual, 1 skip; source (out, in)
+    const int kc = r & 63, m2 = r >> 6;
+    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3);
+    const int blk = 2 * g + (m2 >> 5), ln = (m2 & 31) + 32 * lhs, ks = j >> 3;
+    unsigned short h, m, l;
+    bf3_split1((g ? ws : wr)[r], h, m, l);
+    const int at = (((blk * 4 + ks) * 3) * 64 + ln) * 8 + (j & 7);
+    W2[at] = h;
+    W2[at + 512] = m;
+    W2[at + 1024] = l;
+  }
+  for (int i = tid; i < 128; i += nthreads) BI[i] = i < 64 ? br[i] : bs[i - 64];
+}
+
+// up to FS3_PACK_LAYERS layers per launch (blockIdx.y = layer): images FS3_PACK_F floats apart
+constexpr int FS3_PACK_LAYERS = 32, FS3_PACK_F = FS3_LDS_BYTES / 4;
+struct Fs3PackArgs {
+  const float *wf[FS3_PACK_LAYERS], *wg[FS3_PACK_LAYERS], *wr[FS3_PACK_LAYERS], *ws[FS3_PACK_LAYERS];
+  const float *br[FS3_PACK_LAYERS], *bs[FS3_PACK_LAYERS];
+};
+__global__ __launch_bounds__(256) void fs3_pack_kernel(Fs3PackArgs p, float *dst) {
+  const int l = blockIdx.y;
+  fs3_stage_weights((unsigned char *)(dst + (size_t)l * FS3_PACK_F), p.wf[l], p.wg[l], p.wr[l], p.ws[l], p.br[l], p.bs[l],
+                    blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+__global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fs3_lds[];
+  unsigned short *W1 = (unsigned short *)fs3_lds;                     // [4 blocks][8 k-steps][3 planes][64 lanes][8]
+  unsigned short *W2 = (unsigned short *)(fs3_lds + FS3_W1_BYTES);    // [4 blocks][4 k-steps][3 planes][64 lanes][8]
+  float *BI = (float *)(fs3_lds + FS3_W1_BYTES + FS3_W2_BYTES);      // br | bs
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5;
+#if MVN_EXP == 26  // timing build: the weight staging only, no strip
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.d < 0 ? tb + chunk_t : tb;
+#else
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+#endif
+  const int skip_lo = max(a.t_begin, a.t_skip0);
+  // ---- weights into LDS: the image fs3_pack_kernel wrote once per forward call (a linear 144 KB copy, every load
+  // in flight before the first store), or, without one, converted here (17 us per launch: 48 dependent
+  // global load -> split -> three 2-byte LDS stores per thread; timing build 26)
+  if (a.wpack) {
+    typedef float f4_ __attribute__((ext_vector_type(4)));
+    constexpr int N16 = FS3_LDS_BYTES / 16, PER = (N16 + 511) / 512;
+    const f4_ *src = (const f4_ *)a.wpack;
+    f4_ v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = tid + 512 * i;
+      if (at < N16) v[i] = src[at];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = tid + 512 * i;
+      if (at < N16) ((f4_ *)fs3_lds)[at] = v[i];
+    }
+  } else {
+    fs3_stage_weights(fs3_lds, a.wf, a.wg, a.wr, a.ws, a.br, a.bs, tid, 512);
+  }
+  __syncthreads();
+  const unsigned w1a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)fs3_lds + 16u * lane;
+  // (two base registers per matrix: every plane is then within a ds_read's 16-bit offset of one of them)
+  unsigned w1b = w1a + 2u * 8u * 3072u, w2a = w1a + (unsigned)FS3_W1_BYTES, w2b = w2a + 2u * 4u * 3072u;
+  asm volatile("" : "+v"(w1b), "+v"(w2a), "+v"(w2b));
+  const int cbase = 4 * lh;
+
+  constexpr int RSRC = 0x00020000;  // raw buffer, 32-bit data format (gfx9)
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xin.p + (size_t)b * a.xin.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t thb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.th.p + (size_t)b * a.th.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t sgb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.sg.p + (size_t)b * a.sg.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
+  // timing builds (wrong results; python -m movenet_amd.csrc.build --stamps --exp=N, scripts/exp_fwd.sh): 21 no tanh /
+  // sigmoid stores, 22 no stores, 23 no loads after a wave's first strip, 24 = 22 + 23, 25 no MFMAs (nor splits)
+#if MVN_EXP == 21 || MVN_EXP == 22 || MVN_EXP == 24
+  const bool aux_ok = a.d < 0;  // (never: the stores stay in the code, none is executed)
+#else
+  constexpr bool aux_ok = true;
+#endif
+#if MVN_EXP == 22 || MVN_EXP == 24
+  const bool st_ok = a.d < 0;
+#else
+  constexpr bool st_ok = true;
+#endif
+#if MVN_EXP == 23 || MVN_EXP == 24
+  const bool ld_ok = a.d < 0;
+#else
+  constexpr bool ld_ok = true;
+#endif
+  const bool save = aux_ok && a.th.p != nullptr, has_out = st_ok && a.xout.p != nullptr;
+  int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld;
+
+  // x(t) of a strip is fetched one strip ahead, under the second product of the strip before, and consumed first,
+  // which gives the x(t - d) half, requested at the top of the strip, the first half of the first product to
+  // arrive; the skip accumulator's old values arrive under the second product in the x(t - d) registers
+  // (as in fused_layer64s_kernel).  (Tried: x(t - d) a strip ahead too and the old skip sums at the top of the
+  // strip, both as initial values of the second product's accumulators: 17 us per layer SLOWER -- a wave has 64
+  // vector-memory instructions in flight at most (6-bit vmcnt), a strip issues 224, and 96 loads queued in front
+  // of the 64 stores of the strip before stall the stores.)
+  auto column = [&](int t0_, bool &live_, int &tc_) {
+    const int t_ = t0_ + li;
+    live_ = t_ >= a.t_begin && t_ < te;
+    tc_ = live_ ? t_ : a.t_begin;  // (clamped: dead lanes read a valid column, zeroed afterwards)
+  };
+  float xb1[32];  // x(t) of the current strip: B operand of k-steps 0..3, residual input
+  {
+    bool lv;
+    int tcc;
+    column(tb + 32 * wave, lv, tcc);
+    const int o1 = 4 * (cbase * a.xin.ld + tcc);
+    FS_FENCE(xld4);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+      xb1[j] = lv ? v : 0.f;
+    }
+  }
+
+  constexpr int FS_OOB = (int)0x80000000;
+  for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
+    const int t = t0 + li;
+    bool live;
+    int tc;
+    column(t0, live, tc);
+    const bool skip_live = st_ok && t >= skip_lo && t < te;
+    const int ox0 = 4 * (cbase * a.xin.ld + tc - a.d);
+    const int oth = (save && live) ? 4 * (cbase * a.th.ld + tc) : FS_OOB, oxo = 4 * (cbase * a.xout.ld + tc);
+    const int osk = 4 * (cbase * a.skip.ld + (skip_live ? t : skip_lo));
+    float xn1[32];  // x(t) of the NEXT strip
+    // ---- x(t - d): B operand of k-steps 4..7; later the skip accumulator's old values
+    float xa0[32];
+    FS_FENCE(xld4);
+    if (ld_ok || t0 == tb + 32 * wave) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+        xa0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xa0[j] = xb1[j] * 0.5f;
+    }
+    // (interior strips -- wave-uniform test -- need no masking)
+    if (!(t0 >= a.t_begin && t0 + 32 <= te)) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xa0[j] = live ? xa0[j] : 0.f;
+    }
+    // ---- f | g: four 32 x 32 blocks (f c<32, f c>=32, g c<32, g c>=32), K = 128 = 8 k-steps, the x(t) half first
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#if MVN_BF3_PIPELINED
+    BF3_PRODUCT(8, w1a, w1b, (ks_ < 4 ? xb1[8 * ks_ + e_] : xa0[8 * (ks_ - 4) + e_]));
+#else
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 bh, bm, bl;
+      bf3_split8(ks < 4 ? &xb1[8 * ks] : &xa0[8 * (ks - 4)], bh, bm, bl);
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+        bf3_mfma6(acc[blk], (blk < 2 ? w1a : w1b) + 3072u * (unsigned)((blk & 1) * 8 + ks), bh, bm, bl);
+    }
+#endif
+    // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
+    float z[32];
+    FS_FENCE(thld4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float tv = tanh_fast(acc[h][r]);
+        const float sv = sigmoid_fast(acc[2 + h][r]);
+        z[16 * h + r] = tv * sv;
+        const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, FS_AUX_SAVE);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, FS_AUX_SAVE);
+      }
+    // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's x(t), both
+    // under the MFMAs below
+    FS_FENCE(skld4);
+    if (!a.first_layer && ld_ok) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xa0[16 * h + r] = __uint_as_float(
+              __builtin_amdgcn_raw_buffer_load_b32(skb, osk, (32 * h + (r & 3) + 8 * (r >> 2)) * skld4, 0));
+    }
+    if (ld_ok && t0 + 32 * 8 < te) {
+      bool lv;
+      int tcc;
+      column(t0 + 32 * 8, lv, tcc);
+      const int o1 = 4 * (cbase * a.xin.ld + tcc);
+      FS_FENCE(xld4);
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+        xn1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+      if (!(t0 + 32 * 8 >= a.t_begin && t0 + 32 * 8 + 32 <= te)) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xn1[j] = lv ? xn1[j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xn1[j] = ld_ok ? 0.f : xb1[j];
+    }
+    // ---- residual | skip: four blocks (res c<32, res c>=32, skip k<32, skip k>=32), K = 64 = 4 k-steps
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#if MVN_BF3_PIPELINED
+    BF3_PRODUCT(4, w2a, w2b, z[8 * ks_ + e_]);
+#else
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 bh, bm, bl;
+      bf3_split8(&z[8 * ks], bh, bm, bl);
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+        bf3_mfma6(acc[blk], (blk < 2 ? w2a : w2b) + 3072u * (unsigned)((blk & 1) * 4 + ks), bh, bm, bl);
+    }
+#endif
+    // ---- x' = (y + br) + x(t): x(t) of this lane's channel is input register 16 h + r;
+    // skip (+)= y + bs, columns t - t_base, live from skip_lo
+    FS_FENCE(xold4);
+    FS_FENCE(skld4);
+    {
+      const int oxo_m = (has_out && live) ? oxo : FS_OOB, osk_m = skip_live ? osk : FS_OOB;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[h][r] + BI[c0 + cbase]) + xb1[16 * h + r]), xob, oxo_m,
+                                                c0 * xold4, 0);
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          const float v = acc[2 + h][r] + BI[64 + k0 + cbase];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((a.first_layer || !ld_ok) ? v : xa0[16 * h + r] + v), skb, osk_m,
+                                                k0 * skld4, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) xb1[j] = xn1[j];
+  }
+}
+
+// MOVENET_HIP_FORWARD_MFMA=f32 keeps the fp32-MFMA strip kernel (A/B, tests); read per call
+static bool forward_bf3_enabled() {
+  const char *e = getenv("MOVENET_HIP_FORWARD_MFMA");
+  return !(e && e[0] == 'f');
+}
+
+// the LDS images of layers 0 .. L-1 into `dst` (L x FS3_PACK_F floats), one launch per 32 layers
+static int launch_fs3_pack(const mvn_params *p, int L, float *dst, hipStream_t s) {
+  for (int l0 = 0; l0 < L; l0 += FS3_PACK_LAYERS) {
+    const int n = std::min(FS3_PACK_LAYERS, L - l0);
+    Fs3PackArgs pa;
+    for (int i = 0; i < FS3_PACK_LAYERS; ++i) {
+      const int l = l0 + std::min(i, n - 1);
+      pa.wf[i] = p->filter_w[l]; pa.wg[i] = p->gate_w[l]; pa.wr[i] = p->residual_w[l]; pa.ws[i] = p->skip_w[l];
+      pa.br[i] = p->residual_b[l]; pa.bs[i] = p->skip_b[l];
+    }
+    hipLaunchKernelGGL(fs3_pack_kernel, dim3(8, n), dim3(256), 0, s, pa, dst + (size_t)l0 * FS3_PACK_F);
+  }
+  return check_hip(hipGetLastError(), "fs3_pack");
+}
+
+static int launch_fused_layer64s_bf3(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
+  if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);  // a chunk: whole rounds of the 8 waves' strips
+  const void *fn = (const void *)fused_layer64s_bf3_kernel;
+  const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(fused_layer64s_bf3)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fused_layer64s_bf3_kernel, dim3(chunks * batch), dim3(512), FS3_LDS_BYTES, s, a, chunks, chunk_t);
+  return MVN_OK;
+}
+
+}  // namespace mvn

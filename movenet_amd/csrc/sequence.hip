@@ -29,6 +29,7 @@
 #include "fused_layer.h"
 #include "fused_bwd.h"
 #include "fused_fwd.h"
+#include "fused_fwd_bf3.h"
 
 namespace mvn {
 
@@ -985,7 +986,20 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       if (l == g.L - 1) fp.xout.p = nullptr;  // the last residual output is never used
       fp.th = act_view(save ? buf->th + (size_t)l * g.act : nullptr, batch, C, g.Tp);
       fp.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
-      const int rc2 = launch_fused_layer64p(fp, batch, s);
+      // audio-only layers: the strip kernel on the bf16 matrix cores (fp32 = 3 bf16 planes, fused_fwd_bf3.h)
+      // unless a tile form / the fp32-MFMA strip was asked for, or the rows are longer than a buffer resource spans
+      const bool bf3 = !fp.ctx.p && forward_bf3_enabled() && !getenv("MOVENET_HIP_FORWARD_TILE") &&
+                       fp.xin.ld <= (1 << 22) && fp.skip.ld <= (1 << 22);
+      if (bf3 && (size_t)g.act >= (size_t)g.L * FS3_PACK_F) {
+        // the layers' weights as LDS images (three bf16 planes, the kernel's layout), written once per call into
+        // the z scratch, which this path never touches otherwise: z stays in registers
+        if (l == 0) {
+          const int rc3 = launch_fs3_pack(p, g.L, buf->z, s);
+          if (rc3) return rc3;
+        }
+        fp.wpack = buf->z + (size_t)l * FS3_PACK_F;
+      }
+      const int rc2 = bf3 ? launch_fused_layer64s_bf3(fp, batch, s) : launch_fused_layer64p(fp, batch, s);
       if (rc2) return rc2;
       A += d;
       continue;

@@ -1,4 +1,5 @@
-# Timing builds of the strip forward (python -m movenet_amd.csrc.build --stamps --exp=11 ... --exp=14):
+# Timing builds of the strip forward (python -m movenet_amd.csrc.build --stamps --exp=11 ... --exp=14; the bf16 x 3
+# form: --exp=21 ... --exp=25, EXPS="0 21 22 23 24 25" bash scripts/exp_fwd.sh):
 # per-kernel averages of three training steps under rocprofv3, one library after the other.
 set -e
 cd /tmp && export TMPDIR=/tmp
@@ -8,5 +9,5 @@ for e in ${EXPS:-0 11 12 13 14}; do
   timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/expf$e -o e --output-format csv -- python3 $R/scripts/train_steps.py 3 > $R/gpurun_out/expf$e.log 2>&1
   f=$(find $R/gpurun_out/expf$e -name '*kernel_stats.csv' | head -1)
   echo "== exp $e"
-  test -n "$f" && grep -E "fused_layer64s|bwd_dx_wgfg64|bwd_dz_wgrs64" "$f" | cut -d, -f1-4 | cut -c1-120
+  test -n "$f" && grep -E "fused_layer64s|bwd_dx_wgfg64|bwd_dz_wgrs64|dense_strip" "$f" | cut -d, -f1-4 | cut -c1-120
 done
