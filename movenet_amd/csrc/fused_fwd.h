@@ -322,7 +322,11 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5;
+#if MVN_EXP == 26  // timing build: the weight staging only, no strip
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.d < 0 ? tb + chunk_t : tb;
+#else
   const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+#endif
   const int skip_lo = max(a.t_begin, a.t_skip0);
   // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4].  The loop runs over the SOURCE
   // elements (coalesced reads of the (out, in, tap) / (out, in) tensors) and scatters into LDS.
@@ -621,7 +625,11 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int m_base = blockIdx.y * M;
   const int li = lane & 31, lh = lane >> 5;
+#if MVN_EXP == 26  // timing build: the weight staging only, no strip
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.ldw < 0 ? tb + chunk_t : tb;
+#else
   const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+#endif
   for (int r = tid; r < K * M; r += 512) {  // source order: coalesced
     const int m = TRANSPOSED ? r % M : r / K, k = TRANSPOSED ? r / M : r % K;
     const int kk = k >> 1;

@@ -10,7 +10,7 @@
 // everything above 2^-24 of the product -- what an fp32 multiply keeps.  Six bf16 MFMAs replace the eight fp32
 // MFMAs of a 32 x 32 x 16 block: 2.7 - 5 x less matrix time (scripts/probes/mfma_bf16_split.hip: 2048 -> 470
 // cycles per block and SIMD, the split of the B operand included), with fp32's exponent range (no scaling,
-// no overflow: bf16 has fp32's exponent) and fp32-class error (numpy model in DESIGN 4.2b: max error of a
+// no overflow: bf16 has fp32's exponent) and fp32-class error (numpy model in DESIGN 4.3b: max error of a
 // 256-term product 4.7e-7 of the output range against 5.7e-7 for fp32 sums in numpy's order).
 //
 // Same structure as fused_layer64s_kernel<false> (fused_fwd.h): one wave owns a strip of 32 columns, no

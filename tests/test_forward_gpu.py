@@ -340,9 +340,65 @@ def test_persistent_forward_kernel_matches_per_tile_kernel_and_oracle(monkeypatc
             monkeypatch.setenv("MOVENET_HIP_FORWARD_TILE", tile)
             assert rel_err(outputs(False, train), b_) < 2e-6, (train, tile)
         monkeypatch.delenv("MOVENET_HIP_FORWARD_TILE")
+        # ... and so must the strip kernel on fp32 MFMAs (the default forms each fp32 product from six bf16 MFMAs)
+        monkeypatch.setenv("MOVENET_HIP_FORWARD_MFMA", "f32")
+        assert rel_err(outputs(False, train), b_) < 2e-6, (train, "f32 strip")
+        monkeypatch.delenv("MOVENET_HIP_FORWARD_MFMA")
     if t_len <= 700 and batch <= 4:
         want = O.forward(sd, dims, x, output_unnormalized=True)
         assert rel_err(outputs(False, False), want) < LOGIT_TOL
+
+
+@pytest.mark.parametrize("gain", [1.5, 4.0])
+def test_bf16x3_forward_is_fp32_class(monkeypatch, gain):
+    """csrc/fused_fwd_bf3.h: the audio-only forward layer forms every fp32 product on the bf16 matrix cores --
+    operands split EXACTLY into three bf16 planes, six MFMAs per block, fp32 accumulation.  Measured against the
+    same layer on fp32 MFMAs in TWO summation orders (the strip kernel, MOVENET_HIP_FORWARD_MFMA=f32, and the
+    per-tile kernel, MOVENET_HIP_NO_PERSISTENT_FORWARD=1), at a size that takes the packed weight images (30 layers,
+    4 x 5000 samples): logits, loss and every parameter gradient (the backward pass reads the tanh / sigmoid saved by
+    the forward under test) differ from the fp32 strip by no more than the two fp32 forms differ from each other
+    (x 3; floor: 2e-6 of range for logits, 1e-5 for gradients).  Gain 4 makes the 30-layer stack amplify last-bit
+    differences ~300 x -- there only the comparison with the fp32 pair says anything."""
+    from movenet_amd.utils.weights import make_state_dict
+    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    sd = make_state_dict(**cfg, seed=12, gain=gain, head_gain=2.0)
+    idx = synthetic_indices(4, 5000, 256, 31)
+    x = one_hot(idx, 256).to(DEV)
+
+    def run(form):
+        monkeypatch.delenv("MOVENET_HIP_FORWARD_MFMA", raising=False)
+        monkeypatch.delenv("MOVENET_HIP_NO_PERSISTENT_FORWARD", raising=False)
+        if form == "f32 strip":
+            monkeypatch.setenv("MOVENET_HIP_FORWARD_MFMA", "f32")
+        elif form == "f32 tile":
+            monkeypatch.setenv("MOVENET_HIP_NO_PERSISTENT_FORWARD", "1")
+        m = _model(cfg, sd)
+        m.train(True)
+        logits = m(x, output_unnormalized=False)  # raw logits (Q1: the reference's flag is inverted)
+        w = torch.linspace(-1.0, 1.0, logits.numel(), device=DEV).reshape(logits.shape)
+        loss = (logits * logits * w).mean()   # a loss whose gradient is not tiny anywhere
+        loss.backward()
+        return logits.detach().cpu(), float(loss.detach()), {k: p.grad.detach().cpu() for k, p in m.named_parameters()
+                                                     if p.grad is not None}
+
+    la, loss_a, ga = run("bf16x3")
+    lb, loss_b, gb = run("f32 strip")
+    lc, loss_c, gc = run("f32 tile")
+    monkeypatch.delenv("MOVENET_HIP_NO_PERSISTENT_FORWARD", raising=False)
+    assert torch.isfinite(la).all() and la.abs().max() > 1.0
+    assert rel_err(la, lb) < max(2e-6, 3 * rel_err(lc, lb)), (rel_err(la, lb), rel_err(lc, lb))
+    rms = lambda u, v: float((u.double() - v.double()).pow(2).mean().sqrt())  # noqa: E731
+    assert rms(la, lb) < max(2e-7 * float(lb.abs().max()), 2 * rms(lc, lb)), (rms(la, lb), rms(lc, lb))
+    if gain == 1.5:  # (at gain 4 the loss, a sum with cancellation, moves by 1e-3 between any two forms)
+        assert abs(loss_a - loss_b) < 1e-6 * max(1.0, abs(loss_b))
+    assert set(ga) == set(gb) and len(ga) > 180
+    worst = 0.0
+    for k in ga:
+        e, e0 = rel_err(ga[k], gb[k]), rel_err(gc[k], gb[k])
+        assert e < max(1e-5, 3 * e0), (k, e, e0)
+        worst = max(worst, e)
+    if gain == 1.5:
+        assert rel_err(la, lb) < 2e-6 and worst < 1e-5  # absolute statement where the stack does not amplify
 
 
 @pytest.mark.parametrize("t_len", [64, 63, 1000])
