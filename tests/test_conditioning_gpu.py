@@ -178,20 +178,24 @@ def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypat
             assert rel_err(g, params[k].grad) < 3e-4, k
 
 
-def test_conditioned_rounds_match_generic_kernel():
-    """Video-conditioned generation with several sequences per FOLD pipeline (r3: 20 sequences =
-    16 pipelines, four of them serving two): every sequence reads ITS context column -- greedy
-    indices equal to the GENERIC kernel's (one workgroup per sequence) on the same context."""
+@pytest.mark.parametrize("channels,which,B", [(64, "fold", 20), (64, "pipe", 30), (128, "pipe", 6)])
+def test_conditioned_rounds_match_generic_kernel(channels, which, B):
+    """Video-conditioned generation with several sequences per pipeline (r3): 20 sequences on FOLD's 16
+    pipelines, 30 on PIPE's 24 (C = 64), 6 on the 4 sixty-one-stage pipelines of the C = K = 128 model -- some
+    pipelines serve two sequences, and every sequence must read ITS context column: greedy indices equal to the
+    GENERIC kernel's (one workgroup per sequence) on the same context."""
     from movenet_amd import _native as N
     from movenet_amd.generation import RingGenerator
-    cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
-    sd = {k: v.to(DEV) for k, v in make_state_dict(**cfg, seed=1, gain=2.0, head_gain=6.0).items()
-          if not k.startswith("video_")}
-    rf, B, n_new = O.Dims(**cfg).receptive_fields, 20, 20
+    cfg = dict(layer_size=10, stack_size=3 if channels == 64 else 6, input_channels=256, residual_channels=channels,
+               skip_channels=channels)
+    pipelined = N.GEN_FOLD if which == "fold" else N.GEN_PIPE
+    sd = {k: v.to(DEV) for k, v in make_state_dict(**cfg, seed=1, gain=2.0 if channels == 64 else 1.5,
+                                                   head_gain=6.0).items() if not k.startswith("video_")}
+    rf, n_new = O.Dims(**cfg).receptive_fields, 20
     pidx = synthetic_indices(B, rf, 256, 77).to(DEV)
-    ctx = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 64, rf + n_new)).astype(np.float32)).to(DEV)
+    ctx = torch.from_numpy(np.random.default_rng(5).standard_normal((B, channels, rf + n_new)).astype(np.float32)).to(DEV)
     runs = {}
-    for variant in (N.GEN_GENERIC, N.GEN_FOLD):
+    for variant in (N.GEN_GENERIC, pipelined):
         g = RingGenerator(**cfg, state_dict=sd, batch=B, n_total=rf + n_new, device=DEV, variant=variant,
                           temperature=0.0, context=ctx)
         assert g.variant == variant
@@ -199,8 +203,8 @@ def test_conditioned_rounds_match_generic_kernel():
         g.advance(n_new)
         g.check_errors()
         runs[variant] = g.samples.clone()
-    assert torch.equal(runs[N.GEN_FOLD], runs[N.GEN_GENERIC])
-    plain = RingGenerator(**cfg, state_dict=sd, batch=B, n_total=rf + n_new, device=DEV, variant=N.GEN_FOLD)
+    assert torch.equal(runs[pipelined], runs[N.GEN_GENERIC])
+    plain = RingGenerator(**cfg, state_dict=sd, batch=B, n_total=rf + n_new, device=DEV, variant=pipelined)
     plain.prime(pidx)
     plain.advance(n_new)
-    assert not torch.equal(plain.samples, runs[N.GEN_FOLD])  # the context matters
+    assert not torch.equal(plain.samples, runs[pipelined])  # the context matters
