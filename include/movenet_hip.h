@@ -197,7 +197,9 @@ typedef struct mvn_fwd_buffers {
   float *acts;  /* n_act x (B, C, Tp): layer inputs; acts[0] = causal conv out  */
   float *th;    /* save: L x (B, C, Tp) tanh(f);      else NULL                 */
   float *sg;    /* save: L x (B, C, Tp) sigmoid(g);   else NULL                 */
-  float *z;     /* (B, C, Tp) gated activation scratch                          */
+  float *z;     /* (B, C, Tp) scratch: the gated activation of the unfused layer
+                   kernels; the fused paths keep z on chip and write the layers'
+                   packed weight images here (fused_layer.h, fused_fwd_bf3.h)        */
   float *skip;  /* (B, K, Sp) sum of skips                                      */
   float *a1;    /* (B, Q, Sp) head hidden activation lrelu(conv1(lrelu(skip)))  */
   const float *ctx; /* optional local conditioning (B, C, ctx_ld), column t = time t
