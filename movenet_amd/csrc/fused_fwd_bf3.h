@@ -156,19 +156,6 @@ __device__ __forceinline__ void bf3_mfma6(f32x16 &acc, unsigned wa, const u32x4 
 constexpr int FS3_W1_BYTES = 4 * 8 * 3 * 1024, FS3_W2_BYTES = 4 * 4 * 3 * 1024;  // 96 KB + 48 KB
 constexpr int FS3_LDS_BYTES = FS3_W1_BYTES + FS3_W2_BYTES + 128 * 4;
 
-// v0 = value of (channel c, this lane's column), v1 = (c + 1, this column): after the exchange with the lane pair's
-// other lane the even lane stores (c; t, t + 1), the odd lane (c + 1; t - 1, t) -- `voff` carries the lane's row and
-// even column, `soff` the row block of c
-template <int AUX>
-__device__ __forceinline__ void fs3_store_pair(float v0, float v1, bool odd, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  constexpr int SWAP = 0xB1;  // quad_perm [1, 0, 3, 2]: the value of the lane pair's other lane
-  const unsigned o0 = __builtin_amdgcn_mov_dpp(__float_as_uint(v0), SWAP, 0xF, 0xF, true);
-  const unsigned o1 = __builtin_amdgcn_mov_dpp(__float_as_uint(v1), SWAP, 0xF, 0xF, true);
-  const unsigned lo = odd ? o1 : __float_as_uint(v0), hi = odd ? __float_as_uint(v1) : o0;
-  __builtin_amdgcn_raw_buffer_store_b64(v2u{lo, hi}, rsrc, voff, soff, AUX);
-}
-
 // The layer's weights as the kernel's LDS image: W1 [4 blocks][8 k-steps][3 planes][64 lanes][8 bf16], W2 [4][4][3][64][8],
 // then br | bs as floats.  Input register j of a lane of half lh holds channel (j & 3) + 8 (j >> 2) + 4 lh; k-step ks
 // takes registers 8 ks' .. 8 ks' + 7: ks 0..3 of x(t) (tap 1), ks 4..7 of x(t - d) (tap 0).  `img` may be LDS or global.
@@ -363,43 +350,17 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
     // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
     float z[32];
     FS_FENCE(thld4);
-    const bool interior = t0 >= a.t_begin && t0 + 32 <= te;  // wave-uniform
-#if MVN_EXP != 28
-    if (interior) {
-      // Interior strips store PAIRS: registers r, r + 1 hold channels c, c + 1 of this lane's column; a lane pair
-      // (t, t + 1) exchanges them (one DPP select per register) so that the even lane holds (c; t, t + 1) and the
-      // odd lane (c + 1; t, t + 1): one 8-byte store per lane and register PAIR -- 4 row segments of 128 bytes
-      // per instruction instead of 2, half the store instructions of a strip (a wave has 64 vector-memory
-      // instructions in flight at most, and the stores are what the strip waits for: timing builds 21 / 22).
-      const bool odd = li & 1;
-      const int oth2 = save ? 4 * ((cbase + (odd ? 1 : 0)) * a.th.ld + (tc & ~1)) : FS_OOB;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float tv0 = tanh_fast(acc[h][r]), tv1 = tanh_fast(acc[h][r + 1]);
-          const float sv0 = sigmoid_fast(acc[2 + h][r]), sv1 = sigmoid_fast(acc[2 + h][r + 1]);
-          z[16 * h + r] = tv0 * sv0;
-          z[16 * h + r + 1] = tv1 * sv1;
-          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
-          fs3_store_pair<FS_AUX_SAVE>(tv0, tv1, odd, thb, oth2, c0 * thld4);
-          fs3_store_pair<FS_AUX_SAVE>(sv0, sv1, odd, sgb, oth2, c0 * thld4);
-        }
-    } else
-#endif
-    {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float tv = tanh_fast(acc[h][r]);
-          const float sv = sigmoid_fast(acc[2 + h][r]);
-          z[16 * h + r] = tv * sv;
-          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, FS_AUX_SAVE);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, FS_AUX_SAVE);
-        }
-    }
+      for (int r = 0; r < 16; ++r) {
+        const float tv = tanh_fast(acc[h][r]);
+        const float sv = sigmoid_fast(acc[2 + h][r]);
+        z[16 * h + r] = tv * sv;
+        const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, FS_AUX_SAVE);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, FS_AUX_SAVE);
+      }
     // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's x(t), both
     // under the MFMAs below
     FS_FENCE(skld4);
