@@ -434,7 +434,7 @@ def batch_sweep_lines(dev, sd, rf, rank, n_new=4000):
     out = {}
     dims = N.make_dims(*(CFG[k] for k in ("layer_size", "stack_size", "input_channels", "residual_channels",
                                           "skip_channels")))
-    for B in (64, 128):
+    for B in (64, 128, 184):
         kind, group, variant = auto_plan(dims, B, False)
         kw = dict(state_dict=sd, batch=B, n_total=rf + n_new + n_new // 10 + 1, device=dev, variant=variant,
                   temperature=0.0, seed=0)

@@ -117,15 +117,23 @@ int mvn_output_size(const mvn_dims *dims, int t_len);
                           into the filter/gate matrix of layer j+1 (products formed at pack
                           time): ONE dependent mat-vec + gate per layer instead of two; three
                           layers per stage, ceil(L/3)+1 stages (11 for 30 layers): 16 pipelines
-                          co-resident, each serving up to 8 sequences in turn within one launch
-                          (128 sequences).  Config 2: 14.7 us per step for 16 sequences (PIPE:
-                          17.5), 15.4 for 64, 21.1 for 128 (STREAM: 79): what MVN_GEN_AUTO runs
-                          whenever it holds the batch.                                          */
+                          inside XCDs + 7 across them, each serving up to 8 sequences in turn
+                          within one launch (184 sequences).  Config 2: 14.7 us per step for 16
+                          sequences (PIPE: 17.5), 15.4 for 64, 15.9 for 128, 21.1 for 184 (STREAM:
+                          79): what MVN_GEN_AUTO runs whenever it holds the batch.              */
 
 /* Resolve MVN_GEN_AUTO for `dims` and `batch` sequences per launch; returns the
  * variant or a negative error.  The packed weight layout depends on the variant:
  * pack and generate must be given the same resolved value. */
 int mvn_gen_variant(const mvn_dims *dims, int requested, int batch);
+
+/* Pipelines (workgroup chains with resident weights) a launch of `batch` sequences of the
+ * pipelined `variant` (PIPE, PIPE_F16, FOLD) runs on -- its sequences take turns on them,
+ * ceil(batch / pipelines) each; 0 for the other variants, negative on bad dims.  FOLD at
+ * config 2: `batch` up to 16, 16 up to 80 sequences (whole pipelines inside one XCD: the
+ * pipeline's latency bounds the step), 23 beyond (plus seven across XCDs: the step is
+ * rounds x the stages' service time there).  For cost models (generation.auto_plan). */
+int mvn_gen_launch_pipelines(const mvn_dims *dims, int variant, int batch);
 
 /* Size in floats of the packed weight blob / of the generator state (dilation
  * queues, plus the PIPE variant's hand-off area when the dims allow PIPE). */

@@ -84,7 +84,9 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
 bool fold_ok(const mvn_dims *d);
 int fold_stages(const mvn_dims *d);
 int fold_pipelines(const mvn_dims *d);  // pipelines co-resident on the chip (one sequence each: the fastest step)
-int fold_max_batch(const mvn_dims *d);  // ... each serving up to fold::GMAX sequences in turn
+int fold_pipelines_max(const mvn_dims *d);  // ... plus those the XCDs' left-over CUs form across XCDs (slower hops)
+int fold_max_batch(const mvn_dims *d);  // fold_pipelines_max, each serving up to fold::GMAX sequences in turn
+int fold_launch_pipelines(const mvn_dims *d, int batch);  // pipelines a launch of `batch` sequences runs on
 size_t fold_weights_floats(const mvn_dims *d);  // packed blob without the context section
 size_t fold_hand_floats(const mvn_dims *d, int batch);
 int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s);

@@ -738,6 +738,16 @@ static int device_cus() {
   return cus;
 }
 
+int mvn_gen_launch_pipelines(const mvn_dims *dims, int variant, int batch) {
+  int rc = mvn::validate_dims(dims);
+  if (rc) return rc;
+  if (batch < 1) return 0;
+  if (variant == MVN_GEN_FOLD && mvn::fold_ok(dims)) return mvn::fold_launch_pipelines(dims, batch);
+  if (variant == MVN_GEN_PIPE && mvn::pipe_ok(dims)) return std::min(batch, mvn::pipe_pipelines(dims));
+  if (variant == MVN_GEN_PIPE_F16 && mvn::pipe_h16_ok(dims)) return std::min(batch, mvn::pipe_h16_pipelines(dims));
+  return 0;
+}
+
 int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   int rc = mvn::validate_dims(dims);
   if (rc) return rc;

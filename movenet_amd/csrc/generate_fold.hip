@@ -198,10 +198,21 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
   using namespace fold;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // (xcd, slot) -> (sequence, stage): a pipeline of NS <= 32 stages sits in one XCD (speed only;
-  // every edge verifies its own placement below)
+  // (xcd, slot) -> (pipeline, stage): a pipeline of NS <= 32 stages sits in one XCD (speed only;
+  // every edge verifies its own placement below).  The CUs an XCD has left over behind its whole pipelines
+  // (config 2: 32 - 2 x 11 = 10) form further pipelines ACROSS XCDs (80 CUs: seven more) -- slower hops, which
+  // does not matter where they are used: launches whose step is bound by the stages' service time per turn.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int b = xcd + 8 * (slot / NS), s = slot % NS;
+  const int in_xcd = (PIPE_XCD_CUS / NS) * NS;  // slots of an XCD's whole pipelines
+  int b, s;
+  if (slot < in_xcd) {
+    b = xcd + 8 * (slot / NS);
+    s = slot % NS;
+  } else {
+    const int idx = xcd * (PIPE_XCD_CUS - in_xcd) + (slot - in_xcd);
+    b = 8 * (PIPE_XCD_CUS / NS) + idx / NS;
+    s = idx % NS;
+  }
   if (b >= nb) return;
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // sticky status
   const int L = a.L;
@@ -832,7 +843,20 @@ bool fold_ok(const mvn_dims *d) {
 }
 int fold_stages(const mvn_dims *d) { return (n_layers(d) + fold::LPS - 1) / fold::LPS + 1; }
 int fold_pipelines(const mvn_dims *d) { return 8 * (PIPE_XCD_CUS / fold_stages(d)); }  // co-resident pipelines
-int fold_max_batch(const mvn_dims *d) { return fold::GMAX * fold_pipelines(d); }         // GMAX sequences each
+int fold_pipelines_max(const mvn_dims *d) {  // ... plus the pipelines the XCDs' left-over CUs form across XCDs
+  const int NS = fold_stages(d);
+  return fold_pipelines(d) + 8 * (PIPE_XCD_CUS - (PIPE_XCD_CUS / NS) * NS) / NS;
+}
+int fold_max_batch(const mvn_dims *d) { return fold::GMAX * fold_pipelines_max(d); }     // GMAX sequences each
+// Pipelines a launch of `batch` sequences runs on: one sequence each up to fold_pipelines(d) (the fastest step);
+// rounds on those while the pipeline's latency bounds the step (up to FOLD_LATENCY_ROUNDS each); every pipeline
+// the chip holds beyond that, where the step is rounds x the stages' service time per turn
+constexpr int FOLD_LATENCY_ROUNDS = 5;
+int fold_launch_pipelines(const mvn_dims *d, int batch) {
+  const int p = fold_pipelines(d);
+  if (batch <= p) return batch;
+  return batch <= FOLD_LATENCY_ROUNDS * p ? p : fold_pipelines_max(d);
+}
 size_t fold_weights_floats(const mvn_dims *d) {
   return (size_t)fold::EMB_F + (size_t)(fold_stages(d) - 1) * fold::STAGE_F + fold::HEAD_F;
 }
@@ -879,7 +903,7 @@ int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
                 size_t status_offset_floats, hipStream_t s) {
   using namespace fold;
   int NS = fold_stages(d);
-  const int pipes = std::min(batch, fold_pipelines(d));
+  const int pipes = fold_launch_pipelines(d, batch);
   const bool multi = batch > pipes;
   const void *fn = multi ? (const void *)gen_fold_kernel<true> : (const void *)gen_fold_kernel<false>;
   int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(gen_fold)");
@@ -893,10 +917,10 @@ int fold_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
       check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, lds_bytes),
                 "hipOccupancyMaxActiveBlocksPerMultiprocessor(gen_fold)"))
     return MVN_ERR_LAUNCH;
-  const int slots = (pipes + 7) / 8 * NS;
+  const int slots = pipes <= fold_pipelines(d) ? (pipes + 7) / 8 * NS : PIPE_XCD_CUS;
   if (cus < 8 * PIPE_XCD_CUS || batch > fold_max_batch(d) || per_cu < 1 || slots * 8 > per_cu * cus) {
     set_error("FOLD variant: %d stages per pipeline, %d pipelines of at most %d sequences each on %d CUs (batch %d "
-              "asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : fold_pipelines(d), GMAX, cus, batch);
+              "asked for)", NS, cus < 8 * PIPE_XCD_CUS ? 0 : fold_pipelines_max(d), GMAX, cus, batch);
     return MVN_ERR_UNSUPPORTED;
   }
   // hand-off area layout of the generator state: [granules ...][16 flag words at

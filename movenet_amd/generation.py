@@ -303,11 +303,14 @@ class RingGenerator:
 # as the rounds fit under it, then rounds x the stages' service time per turn.  Keys: (C, variant);
 # values: (us per step with one sequence per pipeline, us per step with several while the latency
 # still bounds it, us per turn, most sequences per pipeline = GMAX of the kernel).
-#   FOLD, config 2:  16 pipelines: 14.7 us for 16, 15.3 for 64, 21.1 for 128
+#   FOLD, config 2:  16 pipelines: 14.7 us for 16, 15.3 for 17 .. 80; beyond 80 sequences 23 pipelines (seven of
+#                    them across XCDs: their slower hops set the latency): 16.4 us for 81 .. 128, 17.9 for 138,
+#                    20.9 for 161, 23.2 for 184 (r2: 53 us for 64, 78 for 128)
 #   PIPE, config 2:  24 pipelines: 17.4 us for 24 .. 96, 25.8 for 144, 34.4 for 192
 #   PIPE, config 5:   4 pipelines: 72.4 us for 4, 73.2 for 5 .. 64 (the turn never bounds it)
 _PIPELINED_US = {(64, N.GEN_FOLD): (14.7, 15.3, 2.64, 8), (64, N.GEN_PIPE): (17.4, 17.6, 4.3, 8),
                  (128, N.GEN_PIPE): (72.4, 73.2, 4.5, 16)}
+_FOLD_CROSS_US = (16.4, 2.95)   # FOLD on all 23 pipelines: latency of a cross-XCD pipeline, us per turn
 # ... and of the best kernel that takes EVERY sequence in one launch; keys: (C, conditioned):
 # STREAM at C=64 without conditioning, GENERIC otherwise
 _T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128, True): 490.0}
@@ -319,8 +322,14 @@ def _launch_step_us(dims, variant: int, n: int):
     if model is None:
         return None
     t_one, t_multi, t_turn, gmax = model
-    pipes = max(1, max_pipe_batch(dims, variant) // gmax)
+    pipes = max(1, N.lib().mvn_gen_launch_pipelines(dims, variant, n))  # (FOLD: 16 up to 80 sequences, 23 beyond)
     rounds = -(-n // pipes)
+    if variant == N.GEN_FOLD:
+        lib = N.lib()
+        every = lib.mvn_gen_launch_pipelines(dims, variant, 1 << 20)     # all the chip holds (config 2: 23)
+        whole = lib.mvn_gen_launch_pipelines(dims, variant, 2 * every)   # those inside one XCD (16)
+        if pipes > whole:                                                # the cross-XCD pipelines too
+            t_multi, t_turn = _FOLD_CROSS_US
     return t_one if rounds <= 1 else max(t_multi, t_turn * rounds)
 
 
@@ -329,10 +338,10 @@ def auto_plan(dims, batch: int, has_context: bool):
     ``("single", 0, variant)`` for one launch or ``("grouped", group, variant)`` for groups of
     ``group`` sequences taking turns on the pipelines of a pipelined variant.
 
-    Chosen on measured per-step cost (the table above).  C=K=64: ONE FOLD launch up to 128 sequences
-    (16 pipelines x 8 rounds), one PIPE launch where its 24 pipelines need fewer rounds (129 .. ~160),
-    then balanced groups of FOLD launches as long as they beat the one-launch kernels (STREAM 78 us /
-    conditioned GENERIC ~0.3 ms for any number).  C=K=128: ONE PIPE launch up to 64 sequences (4
+    Chosen on measured per-step cost (the table above).  C=K=64: ONE FOLD launch up to 184 sequences
+    (16 pipelines up to 80 sequences, 23 beyond, x 8 rounds), then balanced groups of FOLD launches as long
+    as they beat the one-launch kernels (STREAM 78 us / conditioned GENERIC ~0.3 ms for any number); the
+    PIPE kernel's 24 pipelines are the fallback of the C library's AUTO for 185 .. 192.  C=K=128: ONE PIPE launch up to 64 sequences (4
     pipelines x 16 rounds, 73 us whatever the number), groups of up to 64 until GENERIC's 490 us is
     cheaper (beyond 384)."""
     lib = N.lib()
@@ -374,8 +383,8 @@ def max_pipe_batch(dims, variant: int = N.GEN_PIPE) -> int:
 
 
 class GroupedGenerator:
-    """More sequences than one pipelined launch can hold (FOLD: 128 at config 2, PIPE: 24;
-    C = 128: 4): groups of sequences take turns on the pipelines, one launch per group per
+    """More sequences than one pipelined launch can hold (FOLD: 184 at config 2, PIPE: 192;
+    C = 128: 64): groups of sequences take turns on the pipelines, one launch per group per
     ``advance``; ``auto_plan`` picks this as long as the groups' step times add up to less than
     one launch of a kernel that holds every sequence (STREAM: 78 us).
     Same interface as ``RingGenerator``; ``samples`` is one (B, n_total) tensor the groups

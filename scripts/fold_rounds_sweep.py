@@ -1,6 +1,7 @@
 """Step time of the config-2 generator with several sequences per pipeline (gen_fold_kernel<true>):
     python scripts/fold_rounds_sweep.py [n_new]
-Prints us per step of ALL sequences and samples/s for batch 16 .. 128 (FOLD), and STREAM at 128."""
+Prints us per step of ALL sequences and samples/s for batch 16 .. 184 (FOLD: 16 pipelines up to 80 sequences, 23
+beyond), and STREAM at 128."""
 import json
 import os
 import sys
@@ -19,7 +20,7 @@ n_new = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 sd = {k: v.to(dev) for k, v in make_state_dict(**bench.CFG, seed=0).items() if not k.startswith("video_")}
 rf = 3072
 out = {}
-for variant, batches in ((N.GEN_FOLD, (16, 17, 24, 32, 48, 64, 80, 96, 112, 128)), (N.GEN_PIPE, (24,)), (N.GEN_STREAM, (64, 128))):
+for variant, batches in ((N.GEN_FOLD, (16, 17, 24, 32, 48, 64, 80, 81, 96, 112, 128, 138, 161, 184)), (N.GEN_PIPE, (24,)), (N.GEN_STREAM, (64, 128))):
     for B in batches:
         g = RingGenerator(**bench.CFG, state_dict=sd, batch=B, n_total=rf + n_new + n_new // 10 + 1, device=dev,
                           variant=variant, temperature=0.0, seed=0)

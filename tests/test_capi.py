@@ -44,13 +44,16 @@ def test_receptive_fields_and_output_size():
 def test_generate_sizes_and_variants():
     lib = N.lib()
     d2 = N.make_dims(10, 3, 256, 64, 64)
-    # FOLD: 16 eleven-stage pipelines fit the 256 CUs, each serving up to 8 sequences in turn (r3)
+    # FOLD: 16 eleven-stage pipelines inside XCDs + 7 across them (r3), each serving up to 8 sequences in turn
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 16) == N.GEN_FOLD
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 17) == N.GEN_FOLD
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 128) == N.GEN_FOLD
-    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 129) == N.GEN_PIPE   # 24 pipelines x 8 rounds
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 184) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 185) == N.GEN_PIPE   # 24 pipelines x 8 rounds
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 192) == N.GEN_PIPE
     assert lib.mvn_gen_variant(d2, N.GEN_AUTO, 193) == N.GEN_STREAM
+    assert [lib.mvn_gen_launch_pipelines(d2, N.GEN_FOLD, n) for n in (1, 16, 17, 80, 81, 184)] == [1, 16, 16, 16, 23, 23]
+    assert [lib.mvn_gen_launch_pipelines(d2, N.GEN_PIPE, n) for n in (5, 24, 100)] == [5, 24, 24]
+    assert lib.mvn_gen_launch_pipelines(d2, N.GEN_STREAM, 4) == 0
     # PIPE: one workgroup per CU, 32 CUs per XCD: 3 nine-stage pipelines per XCD, 24 in all, each
     # serving up to 8 sequences in turn (r3)
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE, 24) == N.GEN_PIPE
@@ -69,8 +72,8 @@ def test_generate_sizes_and_variants():
     # C=K=64: the hand-off area is sized for the largest pipelined variant (FOLD: 11 stages of
     # 192 granules), the status word follows its granules
     assert lib.mvn_gen_status_offset(d2, 16) == 16 * (3069 * 64 + 11 * 384)
-    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 128) == N.GEN_FOLD
-    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 129) == N.MVN_ERR_UNSUPPORTED
+    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 184) == N.GEN_FOLD
+    assert lib.mvn_gen_variant(d2, N.GEN_FOLD, 185) == N.MVN_ERR_UNSUPPORTED
     assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 64) == N.GEN_PIPE_F16   # 8 pipelines x 8 rounds
     assert lib.mvn_gen_variant(d5, N.GEN_PIPE_F16, 65) == N.MVN_ERR_UNSUPPORTED
     assert lib.mvn_gen_variant(d2, N.GEN_PIPE_F16, 1) == N.MVN_ERR_UNSUPPORTED

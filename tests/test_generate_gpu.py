@@ -211,12 +211,12 @@ def test_config2_pipe_at_full_occupancy():
         g.check_errors()
         runs[variant] = g.samples.clone()
     assert torch.equal(runs[N.GEN_PIPE], runs[N.GEN_STREAM])
-    assert _gen(cfg, sd, 129, rf + 1).variant == N.GEN_PIPE    # AUTO at the C level: 24 pipelines x 8 rounds
+    assert _gen(cfg, sd, 185, rf + 1).variant == N.GEN_PIPE    # AUTO at the C level: 24 pipelines x 8 rounds
     assert _gen(cfg, sd, 193, rf + 1).variant == N.GEN_STREAM  # ... and falls back beyond
     assert _gen(cfg, sd, 24, rf + 1).variant == N.GEN_FOLD     # AUTO: FOLD wherever it holds the batch
-    assert _gen(cfg, sd, 128, rf + 1, variant=N.GEN_FOLD).variant == N.GEN_FOLD  # 16 pipelines x 8 rounds
+    assert _gen(cfg, sd, 184, rf + 1, variant=N.GEN_FOLD).variant == N.GEN_FOLD  # 23 pipelines x 8 rounds
     with pytest.raises(Exception):
-        _gen(cfg, sd, 129, rf + 1, variant=N.GEN_FOLD)
+        _gen(cfg, sd, 185, rf + 1, variant=N.GEN_FOLD)
     with pytest.raises(Exception):
         _gen(cfg, sd, 193, rf + 1, variant=N.GEN_PIPE)  # 24 pipelines x 8 rounds
 
@@ -248,17 +248,19 @@ def test_grouped_pipelines_beyond_one_launch():
     assert torch.equal(out.argmax(1).to(torch.int32), ref.samples)
 
 
-@pytest.mark.parametrize("B", [40, 128])
+@pytest.mark.parametrize("B", [40, 128, 184])
 def test_fold_pipelines_serve_several_sequences_in_turn(B):
     """r3: beyond 16 sequences a FOLD pipeline serves ceil(B / 16) sequences in turn within ONE
     launch (gen_fold_kernel<true>: weights shared, one inbox per sequence and stage).  B = 40 leaves
-    the last round half empty, B = 128 is the full eight rounds.  Greedy indices bit-equal to the
+    the last round half empty; beyond 80 sequences the launch also uses the seven pipelines that the XCDs' left-over
+    CUs form ACROSS XCDs (23 in all: B = 128 is six rounds with the last one partial, B = 184 the full eight on
+    every pipeline).  Greedy indices bit-equal to the
     STREAM kernel, chunked launches equal to one launch, teacher-forced logits within tolerance of
     STREAM's, and sampled draws -- the Philox counter is (seed, step, SEQUENCE), whatever the
     round -- equal to STREAM's on >= 99.9 % of the draws."""
     from movenet_amd.utils.weights import make_state_dict
     sd = make_state_dict(**CFG2, seed=6, gain=2.0, head_gain=6.0)
-    rf, n_new = 3072, (24 if B == 40 else 700)  # (the long run crosses every dilation's queue wrap: 512 steps)
+    rf, n_new = 3072, (24 if B == 40 else 700 if B == 128 else 60)  # (the long run crosses every dilation's queue wrap: 512 steps)
     pidx = synthetic_indices(B, rf, 256, 99).to(DEV)
     ref = _gen(CFG2, sd, B, rf + n_new, variant=N.GEN_STREAM)
     ref.prime(pidx)
@@ -585,15 +587,15 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
 def test_auto_plan_cost_based():
     from movenet_amd.generation import auto_plan
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
-    for n in (1, 16, 20, 32, 64, 128):                                 # one FOLD launch, 1 - 8 rounds
+    for n in (1, 16, 20, 32, 64, 128, 161, 184):                       # one FOLD launch: 16 pipelines, 23 beyond 80 sequences
         assert auto_plan(d2, n, False) == ("single", 0, N.GEN_FOLD)
-    assert auto_plan(d2, 129, False) == ("single", 0, N.GEN_PIPE)     # 24 pipelines x 6 rounds: 25.8 us < 2 x 15.3
-    assert auto_plan(d2, 144, True) == ("single", 0, N.GEN_PIPE)
-    assert auto_plan(d2, 192, False) == ("grouped", 96, N.GEN_FOLD)   # 2 x 15.8 us < 34.4 (PIPE, 8 rounds)
-    assert auto_plan(d2, 256, False) == ("grouped", 128, N.GEN_FOLD)  # 2 x 21.1 us
-    assert auto_plan(d2, 400, False) == ("grouped", 100, N.GEN_FOLD)  # 4 x 18.5 us
-    assert auto_plan(d2, 500, False) == ("single", 0, N.GEN_STREAM)   # 4 x 21.1 us > 78 us
-    assert auto_plan(d2, 500, True) == ("grouped", 125, N.GEN_FOLD)   # no conditioned STREAM kernel
+    assert auto_plan(d2, 144, True) == ("single", 0, N.GEN_FOLD)
+    assert auto_plan(d2, 190, False) == ("grouped", 95, N.GEN_FOLD)   # 2 x 16.4 us < 34.4 (PIPE, 8 rounds)
+    assert auto_plan(d2, 256, False) == ("grouped", 128, N.GEN_FOLD)  # 2 x 17.7 us
+    assert auto_plan(d2, 400, False) == ("grouped", 134, N.GEN_FOLD)  # 3 x 17.7 us
+    assert auto_plan(d2, 500, False) == ("grouped", 167, N.GEN_FOLD)  # 3 x 23.6 us < 78 us
+    assert auto_plan(d2, 600, False) == ("single", 0, N.GEN_STREAM)   # 4 x 20.7 us > 78 us
+    assert auto_plan(d2, 600, True) == ("grouped", 150, N.GEN_FOLD)   # no conditioned STREAM kernel
     for n in (1, 4, 5, 16, 24, 64):                                    # one PIPE launch, 1 - 16 rounds: 73 us
         assert auto_plan(d5, n, False) == ("single", 0, N.GEN_PIPE)
     assert auto_plan(d5, 65, False) == ("grouped", 33, N.GEN_PIPE)    # 2 x 73 us < 490 us
