@@ -330,14 +330,16 @@ struct PendingRsReduce {
 
 template <class WgOp>
 static bool launch_bwd_dz_wgrs64(const FusedBwdAArgs &a, const WgOp &op, int batch, float *bias_scratch,
-                                 float *slab, size_t slab_floats, hipStream_t s,
+                                 size_t bias_floats, float *slab, size_t slab_floats, hipStream_t s,
                                  PendingRsReduce<WgOp> *defer = nullptr) {
   const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
   if (a.t_end <= a.t_begin || batch <= 0) return true;
   int chunks, chunk_t;
   fb_chunks(nt, batch, 2, &chunks, &chunk_t);
   const size_t need = (size_t)chunks * batch * 128 * 64;
-  if (!bias_scratch || !slab || need > slab_floats) return false;
+  // (r3: the bias partials -- 128 per workgroup -- are checked too: the scratch was sized for wgrad2's 512-column
+  // chunks, and short sequences in small batches launch more workgroups than that has room for)
+  if (!bias_scratch || !slab || need > slab_floats || (size_t)chunks * batch * 128 > bias_floats) return false;
   hipLaunchKernelGGL(bwd_dz_wgrs64_kernel, dim3(chunks * batch), dim3(256), 0, s, a, chunks, chunk_t, bias_scratch, slab);
   if (defer) {
     defer->on = true;
@@ -553,14 +555,15 @@ __global__ __launch_bounds__(256, 2) void bwd_dctx_wgctx64_kernel(FusedBwdCArgs 
 }
 
 // Launch geometry of the conditioned pass (the first half's): false when the scratch cannot hold it.
-static bool bwd_dctx_wgctx64_fits(int t_begin, int t_end, int batch, const float *bias_scratch, const float *slab,
-                                  size_t slab_floats, int *chunks, int *chunk_t) {
+static bool bwd_dctx_wgctx64_fits(int t_begin, int t_end, int batch, const float *bias_scratch, size_t bias_floats,
+                                  const float *slab, size_t slab_floats, int *chunks, int *chunk_t) {
   const int nt = t_end - (t_begin & ~TILE_ALIGN);
   *chunks = 0;
   *chunk_t = 0;
   if (t_end <= t_begin || batch <= 0) return true;
   fb_chunks(nt, batch, 2, chunks, chunk_t);
-  return bias_scratch && slab && (size_t)*chunks * batch * 128 * 64 <= slab_floats;
+  return bias_scratch && slab && (size_t)*chunks * batch * 128 * 64 <= slab_floats &&
+         (size_t)*chunks * batch * 128 <= bias_floats;
 }
 static void launch_bwd_dctx_wgctx64(const FusedBwdCArgs &a, const WgCtxOp &op, int batch, float *bias_scratch,
                                     float *slab, int chunks, int chunk_t, hipStream_t s) {

@@ -14,6 +14,9 @@ constexpr int TILE_ALIGN = 31;
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+}  // namespace mvn
+#include "bf3.h"
+namespace mvn {
 
 struct Act {  // (B, ch, ld) view
   float *p;
@@ -475,7 +478,11 @@ __device__ __forceinline__ f4 ld4_edge(const float *p, int t, int lo, int hi) {
   return f4{v[0], v[1], v[2], v[3]};
 }
 
-template <class Op, int NB>
+// BF3: the products on the bf16 matrix cores -- both operands are read from the fp32 tiles eight consecutive time
+// steps per lane (two ds_read_b128) and split into three bf16 planes in registers (bf3.h): per 16 time steps a
+// wave splits its 2 + NB row operands (44 vector instructions each) and issues 12 NB bf16 MFMAs instead of 16 NB
+// fp32 ones -- 384 NB matrix cycles instead of 1024 NB, with the vector work running beside them.
+template <class Op, int NB, bool BF3 = false>
 __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int chunks_per_b,
                                                        float *__restrict__ bias_part, int m_rows_pad,
                                                        float *__restrict__ part, int n_cols_pad) {
@@ -612,6 +619,30 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(Op op, int nblk_n, int c
     // (fence: the scheduler otherwise hoists the row sums of lstore() above the MFMAs and
     // waits for the loads it has just issued)
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BF3) {
+#pragma unroll
+      for (int G = 0; G < W2_T / 16; ++G) {
+        u32x4 ah[2], am[2], al[2], xh[NB], xm[NB], xl[NB];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const f4 v0 = *(const f4 *)&As[64 * wm + 32 * mi + li][16 * G + 2 * h4];
+          const f4 v1 = *(const f4 *)&As[64 * wm + 32 * mi + li][16 * G + 2 * h4 + 4];
+          const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          bf3_split8(v, ah[mi], am[mi], al[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+          const f4 v0 = *(const f4 *)&Xs[32 * NB * wn + 32 * ni + li][16 * G + 2 * h4];
+          const f4 v1 = *(const f4 *)&Xs[32 * NB * wn + 32 * ni + li][16 * G + 2 * h4 + 4];
+          const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          bf3_split8(v, xh[ni], xm[ni], xl[ni]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NB; ++ni) bf3_mfma6r(acc[mi][ni], ah[mi], am[mi], al[mi], xh[ni], xm[ni], xl[ni]);
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < W2_T / 8; ++g) {
       f4 a[2], x[NB];
@@ -792,8 +823,14 @@ static void launch_wgrad2(const Op &op, int m_rows, int n_rows, int batch, float
   const size_t need = (size_t)chunks * batch * mpad * npad;
   float *part = (slab_scratch && need <= slab_floats) ? slab_scratch : nullptr;
   dim3 grid(chunks * batch, mb * nb);
-  hipLaunchKernelGGL((wgrad2_kernel<Op, NB>), grid, dim3(256), 0, s, op, nb, chunks, bias_scratch,
-                     mpad, part, npad);
+  // MOVENET_HIP_WGRAD_MFMA=f32 keeps the fp32-MFMA form (A/B, tests); read per call
+  const char *e = getenv("MOVENET_HIP_WGRAD_MFMA");
+  if (e && e[0] == 'f')
+    hipLaunchKernelGGL((wgrad2_kernel<Op, NB, false>), grid, dim3(256), 0, s, op, nb, chunks, bias_scratch,
+                       mpad, part, npad);
+  else
+    hipLaunchKernelGGL((wgrad2_kernel<Op, NB, true>), grid, dim3(256), 0, s, op, nb, chunks, bias_scratch,
+                       mpad, part, npad);
   if (part)
     hipLaunchKernelGGL(slab_reduce_kernel<Op>, dim3(mpad * npad / 32), dim3(32 * RED_SEG), 0, s, op, part,
                        chunks * batch, mpad, npad);

@@ -1138,12 +1138,23 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   // scratch of the layer weight gradients (wgrad2): per-workgroup partial tiles and bias
   // partial sums, both in da1, which is dead once the head's backward below has run
   float *bias_scratch2 = nullptr, *slab = bwd->da1;
-  size_t slab_floats = (size_t)batch * Q * g.Sp;
+  size_t slab_floats = (size_t)batch * Q * g.Sp, bias2_floats = 0;
   {
-    const size_t need = (size_t)((T + TILE_ALIGN + W2_CHUNK - 1) / W2_CHUNK) * batch * ((C + Kc + 127) / 128 * 128);
+    // room for wgrad2's workgroups (512-column chunks) AND for the fused halves' (one round of two workgroups per
+    // CU whatever the length: up to 2 CUs + batch of them, 128 partial sums each).  r3: the second count was
+    // missing -- at T x batch < 2^18 (the parity tests' sizes, not the configs') the fused first half and the
+    // conditioned pass wrote their bias partials past the end of da1, into whatever tensor came next.
+    const size_t wg2 = (size_t)((T + TILE_ALIGN + W2_CHUNK - 1) / W2_CHUNK) * batch;
+    const size_t wgf = (size_t)2 * fb_device_cus() + batch;
+#if MVN_EXP == 60  // (test build: the sizing before the fix -- MOVENET_DEBUG_GUARD=1 must catch it)
+    const size_t need = wg2 * ((C + Kc + 127) / 128 * 128);
+#else
+    const size_t need = std::max(wg2, wgf) * ((C + Kc + 127) / 128 * 128);
+#endif
     if (need <= slab_floats / 2) {
       slab_floats -= need;
       bias_scratch2 = bwd->da1 + slab_floats;
+      bias2_floats = MVN_EXP == 60 ? (size_t)-1 : need;
     }
   }
   // head weight gradients (wgrad2): slabs + bias partials in dfg
@@ -1298,7 +1309,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       fa.wr = p->residual_w[l]; fa.ws = p->skip_w[l];
       fa.dxo = dxo; fa.dskip = dskip; fa.th = th; fa.sg = sg; fa.dfg = dfg;
       // (all_fused: its reduction runs in the second half's reduce launch)
-      fused_a = launch_bwd_dz_wgrs64(fa, wr, batch, bias_scratch2, slab, slab_floats, s, all_fused ? &pend : nullptr);
+      fused_a = launch_bwd_dz_wgrs64(fa, wr, batch, bias_scratch2, bias2_floats, slab, slab_floats, s,
+                                     all_fused ? &pend : nullptr);
     }
     if (!fused_a) {
       if (bias_scratch2)
@@ -1321,7 +1333,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     // the scratch sizes -- the generic conditioned path computes taps and context rows TOGETHER
     int c_chunks = 0, c_chunk_t = 0;
     const bool fused_c = has_ctx && fused_a && all_fused &&
-                         bwd_dctx_wgctx64_fits(t_lo, T, batch, bias_scratch2, slab, slab_floats, &c_chunks, &c_chunk_t);
+                         bwd_dctx_wgctx64_fits(t_lo, T, batch, bias_scratch2, bias2_floats, slab, slab_floats, &c_chunks,
+                                               &c_chunk_t);
     bool fused_b = false;
     if (fused_bwd && C == 64 && (!has_ctx || fused_c)) {
       // dx and the filter/gate weight gradients from ONE pass over dfg (fused_bwd.h)

@@ -11,6 +11,7 @@ from __future__ import annotations
 from typing import Dict, List, Tuple
 
 import ctypes
+import os
 
 import torch
 
@@ -159,6 +160,31 @@ class _WaveNetFunction(torch.autograd.Function):
         return _grads_for_autograd(ctx_, grads, dctx, _WaveNetFunction.N_FIXED, ctx_.needs_input_grad)
 
 
+class _GuardBands:
+    """Debug allocator (MOVENET_DEBUG_GUARD=1): tensors with a band of sentinel values behind them; ``check``
+    raises if a kernel wrote past the end of one (r3: the fused backward halves' bias partial sums did, for short
+    sequences in small batches -- into whichever tensor the allocator had placed next)."""
+    BAND, SENTINEL = 1 << 18, -1234.5   # 1 MiB of floats behind each tensor
+
+    def __init__(self, device):
+        self.device, self.bands = device, []
+
+    def empty(self, shape, dtype=torch.float32, device=None):
+        n = 1
+        for k in shape:
+            n *= int(k)
+        raw = torch.empty(n + self.BAND, dtype=dtype, device=self.device)
+        raw[n:].fill_(self.SENTINEL)
+        self.bands.append((tuple(shape), raw[n:]))
+        return raw[:n].view(shape)
+
+    def check(self, what: str) -> None:
+        for shape, band in self.bands:
+            bad = int((band != self.SENTINEL).sum().item())
+            if bad:
+                raise RuntimeError(f"movenet_amd: {what} wrote {bad} floats past the end of a {shape} scratch tensor")
+
+
 def _run_backward(ctx_, params, out, dout, fill_dlogit):
     """mvn_backward for a saved forward.  ``dout``: gradient w.r.t. the model output, or None
     when ``fill_dlogit(dlogit, Sp, pad)`` writes the gradient w.r.t. the logits itself (the
@@ -190,13 +216,17 @@ def _run_backward(ctx_, params, out, dout, fill_dlogit):
                          gp.skip_w, gp.skip_b, gp.head1_w, gp.head1_b, gp.head2_w, gp.head2_b,
                          gp.ctx_filter_w, gp.ctx_filter_b, gp.ctx_gate_w, gp.ctx_gate_b)
         f32 = dict(dtype=torch.float32, device=dev)
-        dx_a = torch.empty((B, C, buf.Tp), **f32)
-        dx_b = torch.empty((B, C, buf.Tp), **f32)
-        dfg = torch.empty((B, 2 * C, buf.Tp), **f32)
-        dskip = torch.empty((B, K, buf.Sp), **f32)
-        da1 = torch.empty((B, Q, buf.Sp), **f32)
-        dlogit = torch.empty((B, Q, buf.Sp), **f32)
-        dctx = torch.empty((B, C, buf.Tp), **f32) if ctx_.has_context else None
+        # MOVENET_DEBUG_GUARD=1 (tests): every scratch tensor of the backward pass gets a guard band behind it,
+        # checked after the call -- the library carves its slab / partial-sum scratch out of these tensors
+        guard = _GuardBands(dev) if os.environ.get("MOVENET_DEBUG_GUARD") == "1" else None
+        alloc = torch.empty if guard is None else guard.empty
+        dx_a = alloc((B, C, buf.Tp), **f32)
+        dx_b = alloc((B, C, buf.Tp), **f32)
+        dfg = alloc((B, 2 * C, buf.Tp), **f32)
+        dskip = alloc((B, K, buf.Sp), **f32)
+        da1 = alloc((B, Q, buf.Sp), **f32)
+        dlogit = alloc((B, Q, buf.Sp), **f32)
+        dctx = alloc((B, C, buf.Tp), **f32) if ctx_.has_context else None
         bw = N.BwdBuffers(dx_a.data_ptr(), dx_b.data_ptr(), dfg.data_ptr(), dskip.data_ptr(),
                           da1.data_ptr(), dlogit.data_ptr(),
                           None if dctx is None else dctx.data_ptr())
@@ -210,6 +240,8 @@ def _run_backward(ctx_, params, out, dout, fill_dlogit):
                                  None if dout is None else dout.data_ptr(),
                                  int(ctx_.normalize), int(ctx_.remove_last), _stream_ptr(dev)),
                 "mvn_backward")
+        if guard is not None:
+            guard.check("mvn_backward")
     # (buffers are released with the autograd node; a retained graph may run backward again)
     return grads, (dctx[:, :, :T] if dctx is not None else None)
 

@@ -140,6 +140,9 @@ def test_conditioned_fused_backward_matches_generic_kernels_and_oracle(monkeypat
     import movenet_amd.wavenet as W
     frames, B = 6, 8
     T = 1000 * frames
+    # guard bands behind every scratch tensor of the backward pass (ops._GuardBands): r3 found the fused halves
+    # writing their bias partial sums past the end of one at exactly this size
+    monkeypatch.setenv("MOVENET_DEBUG_GUARD", "1")
     monkeypatch.setattr(W, "MAX_AUDIO_FRAMES", T)
     monkeypatch.setattr(W, "MAX_VIDEO_FRAMES", frames)
     cfg = dict(layer_size=3, stack_size=2, input_channels=256, residual_channels=64, skip_channels=64)

@@ -242,6 +242,7 @@ def test_fused_backward_kernels_match_two_kernel_forms_and_oracle(monkeypatch, l
     assert t_len > dims.receptive_fields
     x = one_hot(synthetic_indices(batch, t_len, 256, 77), 256)
     w = torch.linspace(0.5, 1.5, 256).view(1, 256, 1)
+    monkeypatch.setenv("MOVENET_DEBUG_GUARD", "1")  # guard bands behind the backward pass's scratch tensors (ops.py)
 
     def grads(no_fused):
         if no_fused:
