@@ -6,6 +6,7 @@ Replaces the per-sample window loop of /root/reference/movenet/wavenet.py:217-23
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -192,8 +193,20 @@ class RingGenerator:
             nw = self.lib.mvn_gen_weights_floats(self.dims, self.variant)
             ns = self.lib.mvn_gen_state_floats(self.dims, self.batch)
             self._queue_floats = self.batch * (self.rf - stack_size) * residual_channels
-            self.packed = torch.empty(nw, dtype=torch.float32, device=self.device)
-            self.state = torch.zeros(max(ns, 1), dtype=torch.float32, device=self.device)
+            # (MOVENET_DEBUG_GUARD=1, tests: a band of sentinels behind the packed weights and the state -- queues,
+            # hand-off granules, placement words -- checked in check_errors())
+            self._guard = None
+            if os.environ.get("MOVENET_DEBUG_GUARD") == "1":
+                band, sentinel = 1 << 16, -1234.5
+                raw_p = torch.empty(nw + band, dtype=torch.float32, device=self.device)
+                raw_s = torch.zeros(max(ns, 1) + band, dtype=torch.float32, device=self.device)
+                raw_p[nw:].fill_(sentinel)
+                raw_s[max(ns, 1):].fill_(sentinel)
+                self.packed, self.state = raw_p[:nw], raw_s[:max(ns, 1)]
+                self._guard = (sentinel, raw_p[nw:], raw_s[max(ns, 1):])
+            else:
+                self.packed = torch.empty(nw, dtype=torch.float32, device=self.device)
+                self.state = torch.zeros(max(ns, 1), dtype=torch.float32, device=self.device)
             self.samples = torch.zeros(self.batch, self.n_total, dtype=torch.int32, device=self.device)
         self.t = 0          # number of time steps consumed so far
         self.n_given = 1
@@ -231,6 +244,11 @@ class RingGenerator:
         the last ``reset()`` (workgroups of a pipeline not co-resident, e.g. another process
         occupying CUs).  Every product path calls this before handing samples on."""
         torch.cuda.current_stream(self.device).synchronize()
+        if getattr(self, "_guard", None) is not None:
+            sentinel, *bands = self._guard
+            for band in bands:
+                if bool((band != sentinel).any().item()):
+                    raise RuntimeError("movenet_amd: a generator kernel wrote past the end of its packed weights / state")
         word = self.status_word()
         if word is not None and int(word[0].item()) != 0:
             raise PipeHandoffTimeout(

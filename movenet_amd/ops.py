@@ -78,12 +78,15 @@ class ForwardBuffers:
         S = N.check(lib.mvn_output_size(dims, t_len), "mvn_output_size")
         self.S, self.Tp, self.Sp = S, lib.mvn_padded_len(t_len), lib.mvn_padded_len(S + 31)
         f32 = dict(dtype=torch.float32, device=device)
-        self.acts = torch.empty(((L + 1) if save else 2, batch, C, self.Tp), **f32)
-        self.th = torch.empty((L, batch, C, self.Tp), **f32) if save else None
-        self.sg = torch.empty((L, batch, C, self.Tp), **f32) if save else None
-        self.z = torch.empty((batch, C, self.Tp), **f32)
-        self.skip = torch.empty((batch, K, self.Sp), **f32)
-        self.a1 = torch.empty((batch, Q, self.Sp), **f32)
+        # (MOVENET_DEBUG_GUARD=1: a band of sentinels behind every buffer, checked after mvn_forward)
+        self.guard = _GuardBands(device) if os.environ.get("MOVENET_DEBUG_GUARD") == "1" else None
+        alloc = torch.empty if self.guard is None else self.guard.empty
+        self.acts = alloc(((L + 1) if save else 2, batch, C, self.Tp), **f32)
+        self.th = alloc((L, batch, C, self.Tp), **f32) if save else None
+        self.sg = alloc((L, batch, C, self.Tp), **f32) if save else None
+        self.z = alloc((batch, C, self.Tp), **f32)
+        self.skip = alloc((batch, K, self.Sp), **f32)
+        self.a1 = alloc((batch, Q, self.Sp), **f32)
         self.ctx = ctx
         self.struct = N.FwdBuffers(
             self.acts.data_ptr(), self.th.data_ptr() if save else None,
@@ -118,13 +121,16 @@ def run_forward(dims: N.Dims, sd: Dict[str, torch.Tensor], idx: torch.Tensor, no
     with torch.cuda.device(dev):
         buf = ForwardBuffers(dims, B, T, save, dev, ctx, dense)
         s_out = buf.S - (1 if remove_last else 0)
-        out = torch.empty((B, dims.input_channels, max(s_out, 0)), dtype=torch.float32, device=dev)
+        out = (torch.empty if buf.guard is None else buf.guard.empty)(
+            (B, dims.input_channels, max(s_out, 0)), dtype=torch.float32, device=dev)
         params, keep = pack_params(dims, sd, L)
         fwd = lib.mvn_forward_f16 if f16 else lib.mvn_forward
         N.check(fwd(dims, params, None if dense is not None else idx.data_ptr(),
                     0 if dense is not None else idx.stride(0), B, T, buf.struct,
                     out.data_ptr(), int(normalize), int(remove_last), int(save),
                     _stream_ptr(dev)), "mvn_forward_f16" if f16 else "mvn_forward")
+        if buf.guard is not None:
+            buf.guard.check("mvn_forward")
     buf._keep = keep  # parameter tensors stay alive until the kernels have run
     return out, buf
 
