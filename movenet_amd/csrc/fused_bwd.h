@@ -76,6 +76,9 @@ __device__ __forceinline__ void fb_store16(f4 x, __amdgpu_buffer_rsrc_t r, int v
                                          r, voff, soff, 0);
 }
 
+#ifndef MVN_BWD_WG_BF3
+#define MVN_BWD_WG_BF3 (MVN_EXP != 61)  // (build 61: the weight-gradient products on fp32 MFMAs, right results)
+#endif
 #ifndef MVN_EXP
 #define MVN_EXP 0  // timing builds of the first half (wrong results): 51 no dfg stores, 52 no global loads after a
 #endif             // workgroup's first tile, 53 both
@@ -207,6 +210,8 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
     for (int kk = 0; kk < C; ++kk)
       accd = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
     // ---- weight gradient: (64 x 32) += A (64 x 64 t) z^T
+    // (r3, measured: this product on the bf16 matrix cores as in the second half -- 115.9 against 100.4 us: the
+    // planes do not fit beside this kernel's 248 registers, 13 spill in the tile loop.  It stays on fp32 MFMAs.)
 #pragma unroll
     for (int g = 0; g < TT / 8; ++g) {
       f4 av[2];
@@ -489,6 +494,26 @@ __global__ __launch_bounds__(256, 2) void bwd_dctx_wgctx64_kernel(FusedBwdCArgs 
     for (int kk = 0; kk < C; ++kk)
       accd = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
     // ---- weight gradient: (64 x 32) += dfg (64 x 64 t) ctx^T
+#if MVN_BWD_WG_BF3
+#pragma unroll
+    for (int G = 0; G < TT / 16; ++G) {
+      u32x4 ah[2], am[2], al[2], ch, cm, cl;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f4 v0 = *(const f4 *)&As[64 * wm + 32 * mi + li][16 * G + 2 * h4];
+        const f4 v1 = *(const f4 *)&As[64 * wm + 32 * mi + li][16 * G + 2 * h4 + 4];
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf3_split8(v, ah[mi], am[mi], al[mi]);
+      }
+      {
+        const f4 v0 = *(const f4 *)&Cx[32 * wn + li][16 * G + 2 * h4], v1 = *(const f4 *)&Cx[32 * wn + li][16 * G + 2 * h4 + 4];
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf3_split8(v, ch, cm, cl);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) bf3_mfma6r(accw[mi], ah[mi], am[mi], al[mi], ch, cm, cl);
+    }
+#else
 #pragma unroll
     for (int g = 0; g < TT / 8; ++g) {
       f4 av[2];
@@ -501,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dctx_wgctx64_kernel(FusedBwdCArgs 
         for (int mi = 0; mi < 2; ++mi)
           accw[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[mi], j), f4_get(cv, j), accw[mi], 0, 0, 0);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // ---- this lane owns dctx of channel 32 wc + li at t = 32 wt + 8 q + 4 lh + e: add in LDS
 #pragma unroll
@@ -722,6 +748,57 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     f32x16 accd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+#if MVN_BWD_WG_BF3
+    {
+      // r3: the weight-gradient half of the tile's products on the bf16 matrix cores (bf3.h): per 16 time
+      // steps the wave reads its three row operands eight steps per lane (two ds_read_b128 each), splits them into
+      // three bf16 planes (132 vector instructions) and issues 12 bf16 MFMAs instead of 16 fp32 ones; the dx half
+      // keeps its fp32 MFMAs (its operand is read ACROSS the tile's rows, and its 64 weights per lane would be 96
+      // registers as planes: the kernel has 6 to spare).
+      float (*src)[LD] = half ? A2 : As;
+      float dv[2][8];
+      auto fetch_dv = [&](int g, int S) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dv[S][i] = src[2 * (8 * g + i) + lh][32 * wt + li];
+      };
+      fetch_dv(0, 0);
+#pragma unroll
+      for (int G = 0; G < TT / 16; ++G) {
+        const f4 a0 = *(const f4 *)&As[32 * wm + li][16 * G + 2 * h4], a1 = *(const f4 *)&As[32 * wm + li][16 * G + 2 * h4 + 4];
+        f4 x0[2], x1[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          x0[ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][16 * G + 2 * h4];
+          x1[ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][16 * G + 2 * h4 + 4];
+        }
+        u32x4 ah, am, al, bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * G + gg, S = g & 1;
+          if (g + 1 < TT / 8) fetch_dv(g + 1, S ^ 1);
+          if (spread) gload_part(t0 + TT, g);
+          __builtin_amdgcn_sched_barrier(0);
+          if (gg == 0) {
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            bf3_split8(av, ah, am, al);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const float xv[8] = {x0[ni].x, x0[ni].y, x0[ni].z, x0[ni].w, x1[ni].x, x1[ni].y, x1[ni].z, x1[ni].w};
+              bf3_split8(xv, bh[ni], bm[ni], bl[ni]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            accd = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[S][i], wreg[8 * g + i], accd, 0, 0, 0);
+          if (gg == 1) {
+            bf3_mfma6r(accw[0], ah, am, al, bh[0], bm[0], bl[0]);
+            bf3_mfma6r(accw[1], ah, am, al, bh[1], bm[1], bl[1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#else
     {
       float (*src)[LD] = half ? A2 : As;
       float dv[2][8];
@@ -750,6 +827,7 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores (see the first half)
 #pragma unroll
