@@ -393,6 +393,331 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// The CONDITIONED layer (fused_layer64s_kernel<true>, fused_fwd.h) with what fits of this on it: its f | g product has
+// three K blocks (x(t - d), x(t), context: 96 KB of fp32 MFMA operands, 144 KB as bf16 planes) and does not fit
+// as planes beside anything; the residual | skip product does (48 KB instead of 32: 145 KB in all) and runs on the
+// bf16 matrix cores -- 96 bf16 MFMAs per strip instead of 128 fp32 ones, a quarter of the kernel's fp32 MFMA time
+// gone.  The layer's LDS image (W1 in fp32 MFMA order, W2 as planes, the four bias vectors) is written once per
+// forward call by fsc_pack_kernel and copied linearly (the staging loops of the fp32 kernel: ~8 us per launch).
+// ----------------------------------------------------------------------------------------
+constexpr int FSC_W1_BYTES = 4 * 24 * 1024;                                  // [4 blocks][24 k-step groups][64 lanes][4] floats
+constexpr int FSC_LDS_BYTES = FSC_W1_BYTES + FS3_W2_BYTES + 256 * 4, FSC_PACK_F = FSC_LDS_BYTES / 4;
+struct FscPackArgs {
+  const float *wf[FS3_PACK_LAYERS], *wg[FS3_PACK_LAYERS], *wr[FS3_PACK_LAYERS], *ws[FS3_PACK_LAYERS];
+  const float *br[FS3_PACK_LAYERS], *bs[FS3_PACK_LAYERS];
+  const float *wcf[FS3_PACK_LAYERS], *wcg[FS3_PACK_LAYERS], *bcf[FS3_PACK_LAYERS], *bcg[FS3_PACK_LAYERS];
+};
+__global__ __launch_bounds__(256) void fsc_pack_kernel(FscPackArgs p, float *dst) {
+  const int l = blockIdx.y, tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+  float *W1 = dst + (size_t)l * FSC_PACK_F;
+  unsigned short *W2 = (unsigned short *)((unsigned char *)W1 + FSC_W1_BYTES);
+  float *BI = (float *)((unsigned char *)W1 + FSC_W1_BYTES + FS3_W2_BYTES);
+  constexpr int NK1 = 24;
+  for (int sI = tid; sI < 2 * 8192; sI += nthreads) {  // filter | gate, source (out, in, tap): as fused_layer64s_kernel
+    const int g = sI >> 13, r = sI & 8191;
+    const int tap = r & 1, kc = (r >> 1) & 63, cm = r >> 7;
+    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3), kk = j + 32 * tap;
+    const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
+    W1[((blk * NK1 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? p.wg[l] : p.wf[l])[r];
+  }
+  for (int sI = tid; sI < 2 * 4096; sI += nthreads) {  // context convs, source (out, in)
+    const int g = sI >> 12, r = sI & 4095;
+    const int kc = r & 63, cm = r >> 6;
+    const int lhs = (kc >> 2) & 1, kk = 64 + (kc & 3) + 4 * (kc >> 3);
+    const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
+    W1[((blk * NK1 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? p.wcg[l] : p.wcf[l])[r];
+  }
+  for (int sI = tid; sI < 2 * 4096; sI += nthreads) {  // residual | skip as planes (fs3_stage_weights' layout)
+    const int g = sI >> 12, r = sI & 4095;
+    const int kc = r & 63, m2 = r >> 6;
+    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3);
+    const int blk = 2 * g + (m2 >> 5), ln = (m2 & 31) + 32 * lhs, ks = j >> 3;
+    unsigned short h, m, lo;
+    bf3_split1((g ? p.ws[l] : p.wr[l])[r], h, m, lo);
+    const int at = (((blk * 4 + ks) * 3) * 64 + ln) * 8 + (j & 7);
+    W2[at] = h;
+    W2[at + 512] = m;
+    W2[at + 1024] = lo;
+  }
+  for (int i = tid; i < 256; i += nthreads)
+    BI[i] = i < 64 ? p.br[l][i] : i < 128 ? p.bs[l][i - 64] : i < 192 ? p.bcf[l][i - 128] : p.bcg[l][i - 192];
+}
+
+__global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
+  constexpr bool HAS_CTX = true;
+  constexpr int C = 64, NK1 = 24, W1_F = 4 * NK1 * 256;
+  extern __shared__ __attribute__((aligned(16))) float fs_lds[];
+  float *W1 = fs_lds, *BI = (float *)((unsigned char *)fs_lds + FSC_W1_BYTES + FS3_W2_BYTES);  // BI: br | bs | bcf | bcg
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int li = lane & 31, lh = lane >> 5;
+#if MVN_EXP == 26  // timing build: the weight staging only, no strip
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.d < 0 ? tb + chunk_t : tb;
+#else
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+#endif
+  const int skip_lo = max(a.t_begin, a.t_skip0);
+  // ---- weights into LDS: the image fsc_pack_kernel wrote once per forward call (W1 as fp32 MFMA operands,
+  // [block][k-step / 4][lane][k-step % 4]; W2 as three bf16 planes; the four bias vectors)
+  {
+    typedef float f4_ __attribute__((ext_vector_type(4)));
+    constexpr int N16 = FSC_LDS_BYTES / 16, PER = (N16 + 511) / 512;
+    const f4_ *src = (const f4_ *)a.wpack;
+    f4_ v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = tid + 512 * i;
+      if (at < N16) v[i] = src[at];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = tid + 512 * i;
+      if (at < N16) ((f4_ *)fs_lds)[at] = v[i];
+    }
+  }
+  __syncthreads();
+  const unsigned w1a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)W1 + 16u * lane;
+  unsigned w2a = w1a + (unsigned)FSC_W1_BYTES, w2b = w2a + 2u * 4u * 3072u;
+  asm volatile("" : "+v"(w2a), "+v"(w2b));
+  typedef float fsv4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) fsv4 lds_v4;
+  // channel of accumulator register r of block h in this lane: 32 h + (r & 3) + 8 (r >> 2) + 4 lh
+  const int cbase = 4 * lh;
+
+  // Every global access below is a raw BUFFER access: (a resource per tensor and sequence:
+  // four scalar registers) + (row * ld: one scalar offset) + (one of five per-lane byte offsets).
+  // Formed as 64-bit vector addresses the ~290 accesses of a strip spilled 443 registers; as
+  // scalar row pointers + vector offsets they still cost a 64-bit vector add each and spilled the
+  // scalar file (130 v_writelane / v_readlane per strip).
+  constexpr int RSRC = 0x00020000;  // raw buffer, 32-bit data format (gfx9)
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xin.p + (size_t)b * a.xin.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t thb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.th.p + (size_t)b * a.th.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t sgb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.sg.p + (size_t)b * a.sg.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ctx.p + (size_t)b * a.ctx.sb), 0, 0x7FFFFFFF, RSRC);
+#if MVN_EXP == 13 || MVN_EXP == 14
+  const bool st_ok = a.d < 0;  // (never: the stores stay in the code, none is executed)
+#else
+  constexpr bool st_ok = true;
+#endif
+  const bool save = st_ok && a.th.p != nullptr, has_out = st_ok && a.xout.p != nullptr;
+  int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld, cld4 = 4 * a.ctx.ld;
+  // (row offsets = row * ld are re-formed where they are used, behind a fence on ld: hoisted out of
+  // the strip loop the ~120 products filled the scalar file and were spilled to vector lanes)
+#define FS_FENCE(x) asm volatile("" : "+s"(x))
+
+  // x(t) of a strip (the tap-1 half of the input, 32 registers) is fetched one strip AHEAD, under
+  // the second product of the strip before; the first product consumes it first, which gives the
+  // x(t - d) half, requested at the top of the strip, 128 MFMAs to arrive.  (Without it the wave
+  // counters showed 51 % of the wave cycles waiting for memory: a wave that issues MFMAs back to
+  // back starves the other wave of its SIMD, so the two fall into step and wait together.)
+  auto column = [&](int t0_, bool &live_, int &tc_) {
+    const int t_ = t0_ + li;
+    live_ = t_ >= a.t_begin && t_ < te;
+    tc_ = live_ ? t_ : a.t_begin;  // (clamped: dead lanes read a valid column, zeroed afterwards)
+  };
+  float xb1[32];  // x(t) of the current strip: B operand of k-steps 32..63, residual input
+  if (!HAS_CTX) {
+    bool lv;
+    int tcc;
+    column(tb + 32 * wave, lv, tcc);
+    const int o1 = 4 * (cbase * a.xin.ld + tcc);
+    FS_FENCE(xld4);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+      xb1[j] = lv ? v : 0.f;
+    }
+  }
+
+  // Lanes that must not store (columns outside [t_begin, te), no output tensor) carry an offset
+  // beyond the buffer's num_records: the hardware drops the access -- no exec-mask branch per store.
+  // (Tried: holding a strip's x' and skip sums in registers until after the next strip's first
+  // product, so that no wait on a prefetched load sits right behind 64 fresh stores -- on gfx9 loads
+  // and stores retire through one in-order counter and the compiler's wait at the loop edge was
+  // vmcnt(0).  Measured 131.4 against 131.9 us per layer: the second wave of the SIMD covers it.)
+  constexpr int FS_OOB = (int)0x80000000;
+  for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
+    const int t = t0 + li;
+    bool live;
+    int tc;
+    column(t0, live, tc);
+    const bool skip_live = st_ok && t >= skip_lo && t < te;
+    // per-lane byte offsets (channel part 4 lh of the row + the column)
+    const int ox0 = 4 * (cbase * a.xin.ld + tc - a.d);
+    const int oth = (save && live) ? 4 * (cbase * a.th.ld + tc) : FS_OOB, oxo = 4 * (cbase * a.xout.ld + tc);
+    const int osk = 4 * (cbase * a.skip.ld + (skip_live ? t : skip_lo));
+    float xn1[32];  // without context: x(t) of the NEXT strip; with: ctx(t) of this one (k-steps 64..95)
+    if (HAS_CTX) {
+      const int o1 = 4 * (cbase * a.xin.ld + tc), oc = 4 * (cbase * a.ctx.ld + tc);
+      FS_FENCE(xld4);
+      FS_FENCE(cld4);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+        xb1[j] = live ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cb, oc, ((j & 3) + 8 * (j >> 2)) * cld4, 0));
+        xn1[j] = live ? v : 0.f;
+      }
+    }
+    // ---- x(t - d) of channel kc(j) + 4 lh: B operand of k-steps 0..31; later the skip accumulator's old values
+    float xa0[32];
+    FS_FENCE(xld4);
+#if MVN_EXP == 11 || MVN_EXP == 12 || MVN_EXP == 14
+    if (t0 != tb + 32 * wave) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xa0[j] = xb1[j] * 0.5f;
+    } else
+#endif
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+      xa0[j] = v;
+    }
+    // (interior strips -- wave-uniform test -- need no masking: 32 selects less per strip)
+    if (!(t0 >= a.t_begin && t0 + 32 <= te)) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xa0[j] = live ? xa0[j] : 0.f;
+    }
+    // ---- f | g: four 32 x 32 blocks (f c<32, f c>=32, g c<32, g c>=32), K = 128, the x(t) half first
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int kq = 0; kq < NK1; ++kq) {
+      const int k4 = kq < 8 ? 8 + kq : kq < 16 ? kq - 8 : kq;  // x(t), x(t - d), context
+      fsv4 aw[4];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w1a + 4u * (unsigned)((blk * NK1 + k4) * 256));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              aw[blk][e], k4 >= 16 ? xn1[4 * (k4 - 16) + e] : k4 >= 8 ? xb1[4 * (k4 - 8) + e] : xa0[4 * k4 + e], acc[blk], 0, 0, 0);
+    }
+    // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
+    float z[32];
+    FS_FENCE(thld4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cg_ = 32 * h + (r & 3) + 8 * (r >> 2) + cbase;
+        const float tv = tanh_fast(HAS_CTX ? acc[h][r] + BI[128 + cg_] : acc[h][r]);
+        const float sv = sigmoid_fast(HAS_CTX ? acc[2 + h][r] + BI[192 + cg_] : acc[2 + h][r]);
+        z[16 * h + r] = tv * sv;
+        const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, FS_AUX_SAVE);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), sgb, oth, c0 * thld4, FS_AUX_SAVE);
+      }
+    // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's
+    // x(t), both under the MFMAs below
+    FS_FENCE(skld4);
+#if MVN_EXP == 12 || MVN_EXP == 14
+    if (false) {
+#else
+    if (!a.first_layer) {
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xa0[16 * h + r] = __uint_as_float(
+              __builtin_amdgcn_raw_buffer_load_b32(skb, osk, (32 * h + (r & 3) + 8 * (r >> 2)) * skld4, 0));
+    }
+    const bool more = !HAS_CTX && t0 + 32 * 8 < te;
+    if (HAS_CTX) {
+    } else if (more) {
+      bool lv;
+      int tcc;
+      column(t0 + 32 * 8, lv, tcc);
+      const int o1 = 4 * (cbase * a.xin.ld + tcc);
+      FS_FENCE(xld4);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, o1, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
+        xn1[j] = v;
+      }
+      if (!(t0 + 32 * 8 >= a.t_begin && t0 + 32 * 8 + 32 <= te)) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xn1[j] = lv ? xn1[j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xn1[j] = 0.f;
+    }
+    // ---- residual | skip: four blocks (res c<32, res c>=32, skip k<32, skip k>=32), K = 64
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    BF3_PRODUCT(4, w2a, w2b, z[8 * ks_ + e_]);  // (the residual | skip product on the bf16 matrix cores)
+    // ---- x' = (y + br) + x(t): x(t) of this lane's channel is input register 32 + 16 h + r;
+    // skip (+)= y + bs, columns t - t_base, live from skip_lo
+    FS_FENCE(xold4);
+    FS_FENCE(skld4);
+    {
+      const int oxo_m = (has_out && live) ? oxo : FS_OOB, osk_m = skip_live ? osk : FS_OOB;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[h][r] + BI[c0 + cbase]) + xb1[16 * h + r]), xob, oxo_m,
+                                                c0 * xold4, 0);
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = 32 * h + (r & 3) + 8 * (r >> 2);
+          const float v = acc[2 + h][r] + BI[64 + k0 + cbase];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a.first_layer ? v : xa0[16 * h + r] + v), skb, osk_m, k0 * skld4, 0);
+        }
+    }
+    if (!HAS_CTX) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) xb1[j] = xn1[j];
+    }
+  }
+}
+
+
+static int launch_fsc_pack(const mvn_params *p, int L, float *dst, hipStream_t s) {
+  for (int l0 = 0; l0 < L; l0 += FS3_PACK_LAYERS) {
+    const int n = std::min(FS3_PACK_LAYERS, L - l0);
+    FscPackArgs pa;
+    for (int i = 0; i < FS3_PACK_LAYERS; ++i) {
+      const int l = l0 + std::min(i, n - 1);
+      pa.wf[i] = p->filter_w[l]; pa.wg[i] = p->gate_w[l]; pa.wr[i] = p->residual_w[l]; pa.ws[i] = p->skip_w[l];
+      pa.br[i] = p->residual_b[l]; pa.bs[i] = p->skip_b[l];
+      pa.wcf[i] = p->ctx_filter_w[l]; pa.wcg[i] = p->ctx_gate_w[l]; pa.bcf[i] = p->ctx_filter_b[l]; pa.bcg[i] = p->ctx_gate_b[l];
+    }
+    hipLaunchKernelGGL(fsc_pack_kernel, dim3(8, n), dim3(256), 0, s, pa, dst + (size_t)l0 * FSC_PACK_F);
+  }
+  return check_hip(hipGetLastError(), "fsc_pack");
+}
+static int launch_fused_layer64s_ctxw2(const FusedFwdPArgs &a, int batch, hipStream_t s) {
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
+  if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch, 1, &chunks, &chunk_t, 256);
+  const void *fn = (const void *)fused_layer64s_ctxw2_kernel;
+  const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(fused_layer64s_ctxw2)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fused_layer64s_ctxw2_kernel, dim3(chunks * batch), dim3(512), FSC_LDS_BYTES, s, a, chunks, chunk_t);
+  return MVN_OK;
+}
+
 // MOVENET_HIP_FORWARD_MFMA=f32 keeps the fp32-MFMA strip kernel (A/B, tests); read per call
 static bool forward_bf3_enabled() {
   const char *e = getenv("MOVENET_HIP_FORWARD_MFMA");

@@ -999,6 +999,21 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
         }
         fp.wpack = buf->z + (size_t)l * FS3_PACK_F;
       }
+      // conditioned layers: the strip kernel with its residual | skip product on the bf16 matrix cores and a packed
+      // weight image (same switches; the image needs the z scratch)
+      const bool ctxw2 = fp.ctx.p && forward_bf3_enabled() && !getenv("MOVENET_HIP_FORWARD_TILE") &&
+                         (size_t)g.act >= (size_t)g.L * FSC_PACK_F;
+      if (ctxw2) {
+        if (l == 0) {
+          const int rc3 = launch_fsc_pack(p, g.L, buf->z, s);
+          if (rc3) return rc3;
+        }
+        fp.wpack = buf->z + (size_t)l * FSC_PACK_F;
+        const int rc3 = launch_fused_layer64s_ctxw2(fp, batch, s);
+        if (rc3) return rc3;
+        A += d;
+        continue;
+      }
       const int rc2 = bf3 ? launch_fused_layer64s_bf3(fp, batch, s) : launch_fused_layer64p(fp, batch, s);
       if (rc2) return rc2;
       A += d;
