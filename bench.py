@@ -279,11 +279,12 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
             "flop_per_step_per_gpu": flop_step, "flop_per_token": flop_step / (batch * (t_len - rf)),
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
-                         "note": "fp32 model FLOP against the fp32 MFMA peak.  The backward pass and the head run on "
-                                 "v_mfma_f32_32x32x2_f32; since r3 the audio-only forward layers form each fp32 product "
-                                 "on the bf16 matrix cores (operands split exactly into three bf16 planes, six "
-                                 "v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulation: fp32-class error, "
-                                 "DESIGN 4.3b), which is why a forward layer alone can exceed this peak's rate"}}
+                         "note": "fp32 model FLOP against the fp32 MFMA peak.  Since r3 the forward layers (audio-only: both products; "
+                                 "conditioned: the residual|skip product) and every weight-gradient product (wgrad2, the fused "
+                                 "backward's second half and conditioned pass) form each fp32 product on the bf16 matrix cores "
+                                 "(operands split exactly into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per 32x32x16 "
+                                 "block, fp32 accumulation: fp32-class error, DESIGN 4.3b / 4.4); the data-gradient products and "
+                                 "the head's convolutions run on v_mfma_f32_32x32x2_f32.  That is why a forward layer alone can exceed this peak's rate"}}
 
 
 def trainer_fit_line(dev, steps=8):
