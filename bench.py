@@ -287,11 +287,12 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
                                  "the head's convolutions run on v_mfma_f32_32x32x2_f32.  That is why a forward layer alone can exceed this peak's rate"}}
 
 
-def trainer_fit_line(dev, steps=8):
+def trainer_fit_line(dev, steps=16):
     """The SAME config-2 step driven by the trainer entry point's own loop (Trainer.fit: loader,
     training_step, gradient-norm tracking as the reference's track_grad_norm=2, optimizer,
     OneCycleLR, logging): two epochs of `steps` batches, the second one timed (the first holds
-    code-object loading and allocator growth)."""
+    code-object loading and allocator growth).  (16 steps: an epoch's fixed cost -- the loader's first batch
+    with the GPU idle, the closing synchronise -- is ~5 ms, 0.6 ms per step over 8 steps of 11.5.)"""
     import contextlib
     from movenet_amd.config import ModelConfig, TrainingConfig
     from movenet_amd.pytorch_lightning_trainer import Dance2Music, Trainer
