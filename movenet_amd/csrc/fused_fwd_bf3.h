@@ -718,6 +718,162 @@ static int launch_fused_layer64s_ctxw2(const FusedFwdPArgs &a, int batch, hipStr
   return MVN_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// The head's two forward convolutions (dense_strip_kernel, fused_fwd.h) in the same form: weights as three bf16
+// planes in LDS -- K x M x 6 bytes, 96 KB for conv1 (64 -> 256 rows, all of them in one workgroup) and for conv2
+// in FOUR row blocks of 64 (256 inputs; the fp32 kernel held two blocks of 128: the input is read four times here
+// instead of twice, which the matrix cores' time pays for) -- the strip's input in registers, split eight values
+// at a time, six MFMAs per block and k-step.  `wimg`: the block's LDS image from ds3_pack_kernel, or NULL
+// (converted here).
+//   IN: 0 identity, 1 leaky-ReLU on load;  OUT: 0 y + bias, 1 leaky(y + bias), 2 y * leaky'(ref) (the head's data
+// gradients, weights TRANSPOSED: their leaky-ReLU reference values are requested BEFORE the products -- the fp32
+// strip form had no register left for that and lost to the generic kernel, 454 against 342 us)
+// ----------------------------------------------------------------------------------------
+template <int K, int M, bool TRANSPOSED>
+__device__ __forceinline__ void ds3_stage(unsigned char *img, const float *wmat, int ldw, const float *bias, int m_base,
+                                          int tid, int nthreads) {
+  constexpr int NKS = K / 16;
+  unsigned short *W = (unsigned short *)img;
+  float *BI = (float *)(img + K * M * 6);
+  for (int r = tid; r < K * M; r += nthreads) {  // source order: coalesced (W[m][k] = TRANSPOSED ? wmat[k][m] : wmat[m][k])
+    const int m = TRANSPOSED ? r % M : r / K, k = TRANSPOSED ? r / M : r % K;
+    // input register kk of a lane of half lh holds row 2 kk + lh; k-step ks takes registers 8 ks .. 8 ks + 7
+    const int lhs = k & 1, kk = k >> 1, ks = kk >> 3, e = kk & 7;
+    unsigned short h, mm, l;
+    bf3_split1(TRANSPOSED ? wmat[(size_t)k * ldw + m_base + m] : wmat[(size_t)(m_base + m) * ldw + k], h, mm, l);
+    const int at = ((((m >> 5) * NKS + ks) * 3) * 64 + (m & 31) + 32 * lhs) * 8 + e;
+    W[at] = h;
+    W[at + 512] = mm;
+    W[at + 1024] = l;
+  }
+  for (int i = tid; i < M; i += nthreads) BI[i] = bias ? bias[m_base + i] : 0.f;
+}
+template <int K, int M, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void ds3_pack_kernel(const float *wmat, int ldw, const float *bias, float *dst) {
+  constexpr int IMG_F = (K * M * 6 + M * 4) / 4;
+  ds3_stage<K, M, TRANSPOSED>((unsigned char *)(dst + (size_t)blockIdx.y * IMG_F), wmat, ldw, bias, blockIdx.y * M,
+                              blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+template <int K, int M, int IN, int OUT, bool TRANSPOSED>
+__global__ __launch_bounds__(512, 1) void dense_strip_bf3_kernel(DenseStripArgs a, const float *wimg, int chunks_per_b,
+                                                                 int chunk_t) {
+  static_assert(K * M * 6 + M * 4 <= 160 * 1024 - 1024 && K % 16 == 0 && M % 32 == 0, "the planes fit a CU's LDS");
+  constexpr int NB = M / 32, NKS = K / 16, IMG_BYTES = K * M * 6 + M * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ds3_lds[];
+  float *BI = (float *)(ds3_lds + K * M * 6);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+  const int m_base = blockIdx.y * M;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
+  if (wimg) {
+    typedef float f4_ __attribute__((ext_vector_type(4)));
+    constexpr int N16 = IMG_BYTES / 16, PER = (N16 + 511) / 512;
+    const f4_ *src = (const f4_ *)(wimg + (size_t)blockIdx.y * (IMG_BYTES / 4));
+    f4_ v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = tid + 512 * i;
+      if (at < N16) v[i] = src[at];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = tid + 512 * i;
+      if (at < N16) ((f4_ *)ds3_lds)[at] = v[i];
+    }
+  } else {
+    ds3_stage<K, M, TRANSPOSED>(ds3_lds, a.wmat, a.ldw, a.bias, m_base, tid, 512);
+  }
+  __syncthreads();
+  const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ds3_lds + 16u * lane;
+  constexpr int RSRC = 0x00020000;
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xin.p + (size_t)b * a.xin.sb), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.yout.p + (size_t)b * a.yout.sb + (size_t)m_base * a.yout.ld), 0, 0x7FFFFFFF, RSRC);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.ref.p + (size_t)b * a.ref.sb + (size_t)m_base * a.ref.ld), 0, 0x7FFFFFFF, RSRC);
+  int xld4 = 4 * a.xin.ld, yld4 = 4 * a.yout.ld, rld4 = 4 * a.ref.ld;
+  for (int t0 = tb + 32 * wave; t0 < te; t0 += 32 * 8) {
+    const int t = t0 + li;
+    const bool live = t >= a.t_begin && t < te, out_live = live && t < a.t_out_end;
+    const int tc = live ? t : a.t_begin;
+    const int ox = 4 * (lh * a.xin.ld + tc), oy = 4 * (4 * lh * a.yout.ld + tc), orf = 4 * (4 * lh * a.ref.ld + tc);
+    float rv[OUT == 2 ? NB * 16 : 1];
+    if (OUT == 2) {
+      FS_FENCE(rld4);
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[OUT == 2 ? blk * 16 + r : 0] =
+              __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, orf, (32 * blk + (r & 3) + 8 * (r >> 2)) * rld4, 0));
+    }
+    float xr[K / 2];
+    FS_FENCE(xld4);
+#pragma unroll
+    for (int kk = 0; kk < K / 2; ++kk) {
+      float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox, 2 * kk * xld4, 0));
+      if (IN == 1) v = leaky(v);
+      xr[kk] = live ? v : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4 bh, bm, bl;
+      bf3_split8(&xr[8 * ks], bh, bm, bl);
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        // (base + offset: every plane within a ds_read's 16-bit offset of one of two bases)
+        const unsigned off = 3072u * (unsigned)(blk * NKS + ks);
+        bf3_mfma6(acc[blk], wa + off, bh, bm, bl);
+      }
+    }
+    FS_FENCE(yld4);
+    if (out_live) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m0 = 32 * blk + (r & 3) + 8 * (r >> 2);
+          float y = acc[blk][r];
+          if (OUT == 2) y *= rv[OUT == 2 ? blk * 16 + r : 0] > 0.f ? 1.0f : kLeakySlope;
+          else y += BI[m0 + 4 * lh];
+          if (OUT == 1) y = leaky(y);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), yb, oy, m0 * yld4, 0);
+        }
+    }
+  }
+}
+
+// `m_total` output rows = m_total / M row blocks; `img`: m_total / M packed images (or NULL)
+template <int K, int M, int IN, int OUT, bool TRANSPOSED = false>
+static int launch_dense_strip_bf3(const DenseStripArgs &a, const float *img, int m_total, int batch, hipStream_t s) {
+  const int nt = a.t_end - (a.t_begin & ~TILE_ALIGN);
+  if (a.t_end <= a.t_begin || batch <= 0) return MVN_OK;
+  int chunks, chunk_t;
+  fb_chunks(nt, batch * (m_total / M), 1, &chunks, &chunk_t, 256);
+  const void *fn = (const void *)dense_strip_bf3_kernel<K, M, IN, OUT, TRANSPOSED>;
+  const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(dense_strip_bf3)");
+  if (rc) return rc;
+  hipLaunchKernelGGL((dense_strip_bf3_kernel<K, M, IN, OUT, TRANSPOSED>), dim3(chunks * batch, m_total / M), dim3(512),
+                     K * M * 6 + M * 4, s, a, img, chunks, chunk_t);
+  return MVN_OK;
+}
+template <int K, int M, bool TRANSPOSED = false>
+static void launch_ds3_pack(const float *wmat, int ldw, const float *bias, int m_total, float *dst, hipStream_t s) {
+  hipLaunchKernelGGL((ds3_pack_kernel<K, M, TRANSPOSED>), dim3(8, m_total / M), dim3(256), 0, s, wmat, ldw, bias, dst);
+}
+constexpr size_t DS3_IMG1_F = (64 * 256 * 6 + 256 * 4) / 4, DS3_IMG2_F = (256 * 64 * 6 + 64 * 4) / 4;
+constexpr size_t DS3_IMG_F = DS3_IMG1_F + 4 * DS3_IMG2_F;      // forward: conv1 + conv2's four blocks
+constexpr size_t DS3_BWD_IMG_F = 4 * DS3_IMG2_F + DS3_IMG2_F;  // backward: conv2^T's four blocks + conv1^T
+
 // MOVENET_HIP_FORWARD_MFMA=f32 keeps the fp32-MFMA strip kernel (A/B, tests); read per call
 static bool forward_bf3_enabled() {
   const char *e = getenv("MOVENET_HIP_FORWARD_MFMA");

@@ -1049,6 +1049,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
   }
   // head: a1 = lrelu(W1 lrelu(skip) + b1); logits = W2 a1 + b2   (columns s = 0..S-1)
   Act a1v = act_view(buf->a1, batch, Q, g.Sp);
+  float *head_img = nullptr;  // LDS images of the two head convolutions (bf16 planes), when the bf16 x 3 strips run
   {
     DenseOp<IN_LRELU, OUT_BIAS_LRELU, false> h1;
     h1.K = Kc; h1.t_begin = g.pad; h1.t_end = g.pad + g.S; h1.M = Q; h1.wmat = p->head1_w;
@@ -1059,7 +1060,19 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
       return !(e && e[0] == '1');
     }();
-    if (strip) {
+    // r3: both head convolutions as strip kernels on the bf16 matrix cores (fused_fwd_bf3.h), their LDS images
+    // packed once per call behind the layers' in the z scratch
+    const size_t img_off = (size_t)g.L * std::max(FS3_PACK_F, FSC_PACK_F);
+    if (strip && forward_bf3_enabled() && (size_t)g.act >= img_off + DS3_IMG_F) head_img = buf->z + img_off;
+    if (head_img) {
+      DenseStripArgs da;
+      da.t_begin = h1.t_begin; da.t_end = h1.t_end; da.t_out_end = h1.t_out_end;
+      da.wmat = p->head1_w; da.ldw = Kc; da.bias = p->head1_b; da.xin = skipv; da.yout = a1v; da.ref = a1v;
+      launch_ds3_pack<64, 256>(p->head1_w, Kc, p->head1_b, Q, head_img, s);
+      launch_ds3_pack<256, 64>(p->head2_w, Q, p->head2_b, Q, head_img + DS3_IMG1_F, s);
+      const int rc2 = launch_dense_strip_bf3<64, 256, IN_LRELU, OUT_BIAS_LRELU>(da, head_img, Q, batch, s);
+      if (rc2) return rc2;
+    } else if (strip) {
       DenseStripArgs da;
       da.t_begin = g.pad; da.t_end = g.pad + g.S; da.t_out_end = g.pad + g.S;
       da.wmat = p->head1_w; da.ldw = Kc; da.bias = p->head1_b; da.xin = skipv; da.yout = a1v; da.ref = a1v;
@@ -1080,7 +1093,14 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
       return !(e && e[0] == '1');
     }();
-    if (strip2) {
+    if (head_img && S_out > 0) {
+      // four row blocks of 64 on the bf16 matrix cores (fused_fwd_bf3.h)
+      DenseStripArgs da;
+      da.t_begin = h2.t_begin; da.t_end = h2.t_end; da.t_out_end = h2.t_out_end;
+      da.wmat = p->head2_w; da.ldw = Q; da.bias = p->head2_b; da.xin = a1v; da.yout = h2.yout; da.ref = a1v;
+      const int rc2 = launch_dense_strip_bf3<256, 64, IN_ID, OUT_BIAS>(da, head_img + DS3_IMG1_F, Q, batch, s);
+      if (rc2) return rc2;
+    } else if (strip2) {
       // two row blocks of 128: a1 is read twice instead of once per 64-row block (four times)
       DenseStripArgs da;
       da.t_begin = h2.t_begin; da.t_end = h2.t_end; da.t_out_end = h2.t_out_end;
@@ -1189,6 +1209,13 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   Act dskip = act_view(bwd->dskip, batch, Kc, g.Sp);
   Act a1v = act_view(fwd->a1, batch, Q, g.Sp);
   Act skipv = act_view(fwd->skip, batch, Kc, g.Sp);
+  // the head's data gradients as bf16 x 3 strip kernels (fused_fwd_bf3.h): their LDS images go behind the forward's
+  // in the forward's z scratch, which nothing else touches between the two passes
+  float *bwd_head_img = nullptr;
+  {
+    const size_t off = (size_t)g.L * std::max(FS3_PACK_F, FSC_PACK_F) + DS3_IMG_F;
+    if (Q == 256 && fwd->z && forward_bf3_enabled() && (size_t)g.act >= off + DS3_BWD_IMG_F) bwd_head_img = fwd->z + off;
+  }
   if (!dout) {
     // the caller has filled bwd->dlogit itself (mvn_softmax_ce_backward: the trainer's loss and
     // the model's softmax differentiated in one pass)
@@ -1212,9 +1239,19 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     d2.K = Q; d2.t_begin = g.pad; d2.t_end = g.pad + g.S; d2.M = Q; d2.wmat = p->head2_w; d2.ldw = Q;
     d2.bias = nullptr; d2.xin = dlog; d2.yout = da1; d2.ref = a1v; d2.t_out_end = g.pad + g.S;
     d2.aligned_out = 1;
-    // (the strip form measured 454 us here against 342: its 64 leaky-ReLU reference loads per strip
-    // come after the MFMAs, and there is no register left to fetch them ahead)
-    launch_gemm_staged(d2, Q, batch, s);
+    // (the fp32 strip form measured 454 us here against 342: its 64 leaky-ReLU reference loads per strip
+    // come after the MFMAs, and there is no register left to fetch them ahead.  r3: the bf16 x 3 strip -- four row
+    // blocks of 64, reference values requested before the products, images packed behind the forward's in the z scratch)
+    if (bwd_head_img) {
+      DenseStripArgs da;
+      da.t_begin = d2.t_begin; da.t_end = d2.t_end; da.t_out_end = d2.t_out_end;
+      da.wmat = p->head2_w; da.ldw = Q; da.bias = nullptr; da.xin = dlog; da.yout = da1; da.ref = a1v;
+      launch_ds3_pack<256, 64, true>(p->head2_w, Q, nullptr, Q, bwd_head_img, s);
+      rc = launch_dense_strip_bf3<256, 64, IN_ID, OUT_MUL_DLRELU, true>(da, bwd_head_img, Q, batch, s);
+      if (rc) return rc;
+    } else {
+      launch_gemm_staged(d2, Q, batch, s);
+    }
   }
   {  // head conv1
     WgDenseOp<IN_LRELU> w1;
@@ -1229,8 +1266,17 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     d1.bias = nullptr; d1.xin = da1; d1.yout = dskip; d1.ref = skipv; d1.t_out_end = g.pad + g.S;
     d1.aligned_out = 1;
     // (conv1's data gradient has ONE 64-row output block: the generic kernel already reads da1 once,
-    // and the strip form measured 143 us against its 113)
-    launch_gemm_staged(d1, Kc, batch, s);
+    // and the fp32 strip form measured 143 us against its 113; r3: the bf16 x 3 strip)
+    if (bwd_head_img && Kc == 64) {
+      DenseStripArgs da;
+      da.t_begin = d1.t_begin; da.t_end = d1.t_end; da.t_out_end = d1.t_out_end;
+      da.wmat = p->head1_w; da.ldw = Kc; da.bias = nullptr; da.xin = da1; da.yout = dskip; da.ref = skipv;
+      launch_ds3_pack<256, 64, true>(p->head1_w, Kc, nullptr, Kc, bwd_head_img + 4 * DS3_IMG2_F, s);
+      rc = launch_dense_strip_bf3<256, 64, IN_ID, OUT_MUL_DLRELU, true>(da, bwd_head_img + 4 * DS3_IMG2_F, Kc, batch, s);
+      if (rc) return rc;
+    } else {
+      launch_gemm_staged(d1, Kc, batch, s);
+    }
   }
   // layers, last to first
   int A_lo[4096];
