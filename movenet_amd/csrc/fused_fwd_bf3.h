@@ -875,6 +875,12 @@ constexpr size_t DS3_IMG_F = DS3_IMG1_F + 4 * DS3_IMG2_F;      // forward: conv1
 constexpr size_t DS3_BWD_IMG_F = 4 * DS3_IMG2_F + DS3_IMG2_F;  // backward: conv2^T's four blocks + conv1^T
 
 // MOVENET_HIP_FORWARD_MFMA=f32 keeps the fp32-MFMA strip kernel (A/B, tests); read per call
+// MOVENET_HIP_HEAD_MFMA=f32 keeps the head's fp32 kernels (strips for the convolutions, the staged kernel for their
+// data gradients); read per call
+static bool head_bf3_enabled() {
+  const char *e = getenv("MOVENET_HIP_HEAD_MFMA");
+  return !(e && e[0] == 'f');
+}
 static bool forward_bf3_enabled() {
   const char *e = getenv("MOVENET_HIP_FORWARD_MFMA");
   return !(e && e[0] == 'f');

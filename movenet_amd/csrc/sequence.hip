@@ -1063,7 +1063,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     // r3: both head convolutions as strip kernels on the bf16 matrix cores (fused_fwd_bf3.h), their LDS images
     // packed once per call behind the layers' in the z scratch
     const size_t img_off = (size_t)g.L * std::max(FS3_PACK_F, FSC_PACK_F);
-    if (strip && forward_bf3_enabled() && (size_t)g.act >= img_off + DS3_IMG_F) head_img = buf->z + img_off;
+    if (strip && forward_bf3_enabled() && head_bf3_enabled() && (size_t)g.act >= img_off + DS3_IMG_F) head_img = buf->z + img_off;
     if (head_img) {
       DenseStripArgs da;
       da.t_begin = h1.t_begin; da.t_end = h1.t_end; da.t_out_end = h1.t_out_end;
@@ -1214,7 +1214,8 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   float *bwd_head_img = nullptr;
   {
     const size_t off = (size_t)g.L * std::max(FS3_PACK_F, FSC_PACK_F) + DS3_IMG_F;
-    if (Q == 256 && fwd->z && forward_bf3_enabled() && (size_t)g.act >= off + DS3_BWD_IMG_F) bwd_head_img = fwd->z + off;
+    if (Q == 256 && fwd->z && forward_bf3_enabled() && head_bf3_enabled() && (size_t)g.act >= off + DS3_BWD_IMG_F)
+      bwd_head_img = fwd->z + off;
   }
   if (!dout) {
     // the caller has filled bwd->dlogit itself (mvn_softmax_ce_backward: the trainer's loss and
