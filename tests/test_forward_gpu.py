@@ -355,15 +355,15 @@ def test_bf16x3_forward_is_fp32_class(monkeypatch, gain):
     """csrc/fused_fwd_bf3.h: the audio-only forward layer forms every fp32 product on the bf16 matrix cores --
     operands split EXACTLY into three bf16 planes, six MFMAs per block, fp32 accumulation.  Measured against the
     same layer on fp32 MFMAs in TWO summation orders (the strip kernel, MOVENET_HIP_FORWARD_MFMA=f32, and the
-    per-tile kernel, MOVENET_HIP_NO_PERSISTENT_FORWARD=1), at a size that takes the packed weight images (30 layers,
-    4 x 5000 samples): logits, loss and every parameter gradient (the backward pass reads the tanh / sigmoid saved by
+    per-tile kernel, MOVENET_HIP_NO_PERSISTENT_FORWARD=1), at a size that takes the packed weight images of the layers
+    AND of the head's bf16 x 3 strip kernels (30 layers, 5 x 5000 samples, 1929 ragged output columns): logits, loss and every parameter gradient (the backward pass reads the tanh / sigmoid saved by
     the forward under test) differ from the fp32 strip by no more than the two fp32 forms differ from each other
     (x 3; floor: 2e-6 of range for logits, 1e-5 for gradients).  Gain 4 makes the 30-layer stack amplify last-bit
     differences ~300 x -- there only the comparison with the fp32 pair says anything."""
     from movenet_amd.utils.weights import make_state_dict
     cfg = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
     sd = make_state_dict(**cfg, seed=12, gain=gain, head_gain=2.0)
-    idx = synthetic_indices(4, 5000, 256, 31)
+    idx = synthetic_indices(5, 5000, 256, 31)  # (5 x 64 x 5024 floats of z scratch: the layers' AND the head's images fit)
     x = one_hot(idx, 256).to(DEV)
 
     def run(form):
