@@ -679,6 +679,105 @@ __global__ __launch_bounds__(64) void embed_grad64_kernel(const int32_t *__restr
   f4 *dst = (f4 *)(part + ((size_t)blockIdx.x * gridDim.y + b) * ((size_t)2 * Q * 64) + ((size_t)tap * Q + qbase) * 64);
   for (int i = lane; i < QP * 16; i += 64) dst[i] = ((const f4 *)tab)[i];
 }
+// r3: the same gradient as a PRODUCT on the bf16 matrix cores -- dW[tap][q][c] = sum_t onehot[q][t - 1 + tap] dx0[c][t].
+// The one-hot operand is built in registers from the tile's class indices (a lane owns class row q: eight compares
+// per operand; 1.0 is exact in the top bf16 plane, the other two planes are zero), dx0 is split into its three
+// planes (bf3.h): three MFMAs per block, every product exact, fp32 accumulation.  Workgroup = 4 waves on a chunk of
+// EG64_CHUNK steps in tiles of 64; wave w owns classes [64 w, +64) of both taps and all 64 channels (128
+// accumulator registers); slabs in embed_grad64_kernel's format.  Q = 256 only.
+__global__ __launch_bounds__(256, 2) void embed_grad64_mfma_kernel(const int32_t *__restrict__ idx, int idx_stride, Act dx0,
+                                                                  int T, float *__restrict__ part) {
+  constexpr int Q = 256, LD = W2_LD, TT = W2_T;
+  __shared__ __attribute__((aligned(16))) float Xs[64][LD];
+  __shared__ __attribute__((aligned(16))) int sidx[TT + 8];  // classes of steps t0 - 1 .. t0 + 63 (then padding)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y, t_begin = blockIdx.x * EG64_CHUNK, t_end = min(T, t_begin + EG64_CHUNK);
+  const int32_t *ib = idx + (size_t)b * idx_stride;
+  f32x16 acc[2][2][2];  // [tap][class block][channel block]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+  const int srow = tid >> 4, st = 4 * (tid & 15);
+  // the next tile's dx0 values and classes are fetched into registers under this tile's products
+  f4 nv[4];
+  int ncls = -1;
+  auto fetch = [&](int t0) {
+    const int t = t0 + st;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f4 v = ldg4(dx0.at(b, 16 * p + srow, 0) + min(t, dx0.ld - 4));
+      if (t + 3 >= t_end) {
+        v.x = t < t_end ? v.x : 0.f;
+        v.y = t + 1 < t_end ? v.y : 0.f;
+        v.z = t + 2 < t_end ? v.z : 0.f;
+        v.w = t + 3 < t_end ? v.w : 0.f;
+      }
+      nv[p] = v;
+    }
+    if (tid < TT + 1) {
+      const int u = t0 - 1 + tid;  // class of step u, -1 where there is none
+      ncls = (u >= 0 && u < t_end) ? min(max(ib[u], 0), Q - 1) : -1;
+    }
+  };
+  fetch(t_begin);
+  for (int t0 = t_begin; t0 < t_end; t0 += TT) {
+    __syncthreads();  // the tile before has been read
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *(f4 *)&Xs[16 * p + srow][st] = nv[p];
+    if (tid < TT + 1) sidx[tid] = ncls;
+    if (t0 + TT < t_end) fetch(t0 + TT);
+    __syncthreads();
+#pragma unroll
+    for (int G = 0; G < TT / 16; ++G) {
+      // channel operands: eight consecutive steps of row 32 cb + li, three planes
+      u32x4 xh[2], xm[2], xl[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const f4 v0 = *(const f4 *)&Xs[32 * cb + li][16 * G + 8 * lh], v1 = *(const f4 *)&Xs[32 * cb + li][16 * G + 8 * lh + 4];
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf3_split8(v, xh[cb], xm[cb], xl[cb]);
+      }
+      // the nine classes of steps 16 G + 8 lh - 1 .. + 7 (tap 0 reads e, tap 1 reads e + 1)
+      int cls[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) cls[e] = sidx[16 * G + 8 * lh + e];
+#pragma unroll
+      for (int tap = 0; tap < 2; ++tap)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int qrow = 64 * wave + 32 * rb + li;
+          u32x4 oh;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            oh[i] = (cls[2 * i + tap] == qrow ? 0x3F80u : 0u) | (cls[2 * i + 1 + tap] == qrow ? 0x3F800000u : 0u);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x16 &c = acc[tap][rb][cb];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oh), __builtin_bit_cast(bf16x8, xl[cb]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oh), __builtin_bit_cast(bf16x8, xm[cb]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oh), __builtin_bit_cast(bf16x8, xh[cb]), c, 0, 0, 0);
+          }
+        }
+    }
+  }
+  float *dst = part + ((size_t)blockIdx.x * gridDim.y + b) * ((size_t)2 * Q * 64);
+#pragma unroll
+  for (int tap = 0; tap < 2; ++tap)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = 64 * wave + 32 * rb + acc_row(r, lane), c = 32 * cb + li;
+          dst[((size_t)tap * Q + qq) * 64 + c] = acc[tap][rb][cb][r];
+        }
+}
 struct EmbedSlabOp64 {  // slab word (tap * Q + q, c) -> the (C, Q, 2) table
   float *dcw;
   int Q;
@@ -1471,11 +1570,21 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     const int chunks64 = (T + EG64_CHUNK - 1) / EG64_CHUNK;
     if (C == 64 && Q % EG64_PARTS == 0 && (size_t)Q / EG64_PARTS * 64 * sizeof(float) <= 64 * 1024 && slab &&
         (size_t)chunks64 * batch * 2 * Q * 64 <= slab_floats) {
-      const size_t lds = (size_t)Q / EG64_PARTS * 64 * sizeof(float) + EG64_CHUNK * sizeof(int);
-      rc = ensure_max_dynamic_lds((const void *)embed_grad64_kernel, "hipFuncSetAttribute(embed_grad64)");
-      if (rc) return rc;
-      hipLaunchKernelGGL(embed_grad64_kernel, dim3(chunks64, batch, 2 * EG64_PARTS), dim3(64), lds, s, index, index_stride,
-                         act_view(dxo_p, batch, C, g.Tp), Q, T, slab);
+      // MOVENET_HIP_EMBED_GRAD=scalar keeps the LDS read-modify-write kernel (A/B, tests); Q = 256: the product form
+      const bool mfma_form = Q == 256 && [] {
+        const char *e = getenv("MOVENET_HIP_EMBED_GRAD");
+        return !(e && e[0] == 's');
+      }();
+      if (mfma_form) {
+        hipLaunchKernelGGL(embed_grad64_mfma_kernel, dim3(chunks64, batch), dim3(256), 0, s, index, index_stride,
+                           act_view(dxo_p, batch, C, g.Tp), T, slab);
+      } else {
+        const size_t lds = (size_t)Q / EG64_PARTS * 64 * sizeof(float) + EG64_CHUNK * sizeof(int);
+        rc = ensure_max_dynamic_lds((const void *)embed_grad64_kernel, "hipFuncSetAttribute(embed_grad64)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(embed_grad64_kernel, dim3(chunks64, batch, 2 * EG64_PARTS), dim3(64), lds, s, index, index_stride,
+                           act_view(dxo_p, batch, C, g.Tp), Q, T, slab);
+      }
       EmbedSlabOp64 eo;
       eo.dcw = gr->causal_w; eo.Q = Q;
       hipLaunchKernelGGL(slab_reduce_kernel<EmbedSlabOp64>, dim3((unsigned)(2 * Q * 64 / 32)), dim3(32 * RED_SEG), 0, s,
