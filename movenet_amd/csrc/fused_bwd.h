@@ -76,6 +76,9 @@ __device__ __forceinline__ void fb_store16(f4 x, __amdgpu_buffer_rsrc_t r, int v
                                          r, voff, soff, 0);
 }
 
+#ifndef MVN_BWD_DX_BF3
+#define MVN_BWD_DX_BF3 (MVN_EXP != 61 && MVN_EXP != 63)  // (build 63: the dx products of the second half on fp32 MFMAs)
+#endif
 #ifndef MVN_BWD_WG_BF3
 #define MVN_BWD_WG_BF3 (MVN_EXP != 61)  // (build 61: the weight-gradient products on fp32 MFMAs, right results)
 #endif
@@ -637,6 +640,25 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   const int tb = (a.t_out0 & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const bool has_dxo = a.dxo.p != nullptr;
 
+#if MVN_BWD_DX_BF3
+  // ---- dx on the bf16 matrix cores (r3): wave -> (tap half, K half kh, 32-channel block wc); it forms BOTH 32-step
+  // blocks of the tile over its 64 of the tap's 128 rows, so that its weights are 4 k-steps x 3 planes = 48
+  // registers (all 128 rows would be 96; as fp32 MFMA operands they were 64) and the two K halves meet in the
+  // staging tile.  B operand: W_tap[o][32 wc + li] for o = 64 kh + 16 j + 8 lh + e, e < 8, as planes.
+  const int half = wave >> 2, kh = (wave >> 1) & 1, wc = wave & 1;
+  u32x4 wp[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = 64 * kh + 16 * j + 8 * lh + e;
+      const float *src = o < C ? a.wf : a.wg;
+      wv[e] = src[((size_t)(o & (C - 1)) * C + 32 * wc + li) * 2 + (half ? 0 : 1)];
+    }
+    bf3_split8(wv, wp[j][0], wp[j][1], wp[j][2]);
+  }
+#else
   // ---- dx: wave -> (tap half, 32 u x 32 c block); B operand W_tap[o][32 wc + li], o = 2 kk + lh
   const int half = wave >> 2, wt = (wave >> 1) & 1, wc = wave & 1;
   float wreg[C];
@@ -646,6 +668,7 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     const float *src = o < C ? a.wf : a.wg;
     wreg[kk] = src[((size_t)(o & (C - 1)) * C + 32 * wc + li) * 2 + (half ? 0 : 1)];
   }
+#endif
   // ---- weight gradient: wave -> rows [32 (wave >> 1), +32), columns [64 (wave & 1), +64)
   const int wm = wave >> 1, wn = wave & 1;
   f32x16 accw[2];
@@ -745,6 +768,52 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     // steps of 8 + 8 MFMAs.  The LDS operands of step g + 1 are requested BEFORE the MFMAs of
     // step g (two statically named register sets): left to the scheduler every pair of MFMAs
     // waited out the ds_read issued right in front of it.
+#if MVN_BWD_DX_BF3
+    f32x16 accd2[2];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd2[ub][r] = 0.f;
+    {
+      // per 16 time steps: the weight-gradient products of those steps (12 bf16 MFMAs, three operand splits) and
+      // one of this wave's four dx k-steps for both 32-step blocks (12 bf16 MFMAs, two operand splits: the operand
+      // is read ACROSS the tile's rows, eight ds_read_b32 per block); the next tile's loads in parts in between
+      float (*src)[LD] = half ? A2 : As;
+#pragma unroll
+      for (int G = 0; G < TT / 16; ++G) {
+        if (spread) {
+          gload_part(t0 + TT, 2 * G);
+          gload_part(t0 + TT, 2 * G + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const f4 a0 = *(const f4 *)&As[32 * wm + li][16 * G + 2 * h4], a1 = *(const f4 *)&As[32 * wm + li][16 * G + 2 * h4 + 4];
+          const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          u32x4 ah, am, al;
+          bf3_split8(av, ah, am, al);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const f4 x0 = *(const f4 *)&Xs[64 * wn + 32 * ni + li][16 * G + 2 * h4];
+            const f4 x1 = *(const f4 *)&Xs[64 * wn + 32 * ni + li][16 * G + 2 * h4 + 4];
+            const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            u32x4 bh, bm, bl;
+            bf3_split8(xv, bh, bm, bl);
+            bf3_mfma6r(accw[ni], ah, am, al, bh, bm, bl);
+          }
+        }
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+          float dv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dv[e] = src[64 * kh + 16 * G + 8 * lh + e][32 * ub + li];
+          u32x4 dh, dm, dl;
+          bf3_split8(dv, dh, dm, dl);
+          bf3_mfma6r(accd2[ub], dh, dm, dl, wp[G][0], wp[G][1], wp[G][2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#else
     f32x16 accd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accd[r] = 0.f;
@@ -828,13 +897,39 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
       }
     }
 #endif
+#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores (see the first half)
+#if MVN_BWD_DX_BF3
+    // the two K halves of a tap half meet in the staging tile: kh = 0 stores, kh = 1 adds behind a barrier (a lane
+    // owns the same elements in both)
+    if (kh == 0) {
+#pragma unroll
+      for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f4 *)&St[64 * half + 32 * wc + li][32 * ub + 8 * q + h4] =
+              f4{accd2[ub][4 * q], accd2[ub][4 * q + 1], accd2[ub][4 * q + 2], accd2[ub][4 * q + 3]};
+    }
+    __syncthreads();
+    if (kh == 1) {
+#pragma unroll
+      for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f4 *p4 = (f4 *)&St[64 * half + 32 * wc + li][32 * ub + 8 * q + h4];
+          const f4 o4 = *p4;
+          *p4 = f4{o4.x + accd2[ub][4 * q], o4.y + accd2[ub][4 * q + 1], o4.z + accd2[ub][4 * q + 2], o4.w + accd2[ub][4 * q + 3]};
+        }
+    }
+    __syncthreads();  // the dx halves are staged AND every wave has read the operand tiles
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *(f4 *)&St[64 * half + 32 * wc + li][32 * wt + 8 * q + h4] =
           f4{accd[4 * q], accd[4 * q + 1], accd[4 * q + 2], accd[4 * q + 3]};
     __syncthreads();  // the dx halves are staged AND every wave has read the operand tiles
+#endif
     {
       // rows srow + 32 p (p < 2), columns t0 + st .. +3 inside [t_out0, te)
       const int t = t0 + st;
