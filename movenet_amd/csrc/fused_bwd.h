@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
     // ---- weight gradient: (64 x 32) += A (64 x 64 t) z^T
     // (r3, measured: this product on the bf16 matrix cores as in the second half -- 115.9 against 100.4 us: the
     // planes do not fit beside this kernel's 248 registers, 13 spill in the tile loop.  It stays on fp32 MFMAs.)
+    // (... and the dz product above with its K split between wave pairs as in the second half's dx: 111.3 against
+    // 104.9 us -- this kernel is bound by its barriers and its bytes, a third barrier per tile costs more than the
+    // matrix time it saves.)
 #pragma unroll
     for (int g = 0; g < TT / 8; ++g) {
       f4 av[2];
