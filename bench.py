@@ -272,7 +272,8 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
     return {"metric": "train-step tokens/sec", "value": tokens_per_step * steps / dt, "unit": "tokens/s",
             "workload": wl["name"], "conditioned": bool(frames),
             "ms_per_step": dt / steps * 1e3, "global_batch": world * batch, "seq_len": t_len,
-            "tokens_per_step": tokens_per_step, "optimizer": "AdamW (FlatAdamW, one launch)", "dtype": "f32",
+            "tokens_per_step": tokens_per_step, "optimizer": "AdamW (FlatAdamW, one launch)",
+            "dtype": "f32 (tensors, accumulation and results; most products formed exactly from three bf16 planes per operand)",
             "loss": float(loss.detach()), "optimizer_launches_per_step": opt.last_launches,
             "param_sha256_per_rank": digests, "allreduce_path": sync.last_path,
             "allreduce_floats": sync.last_floats,
