@@ -548,6 +548,38 @@ __global__ void embed_kernel(const float *__restrict__ cw, const int32_t *__rest
   *x0.at(b, c, t) = v;
 }
 
+// ... with the channel's two table rows (Q x 2 floats) in LDS and four steps per thread (r3: the global gathers of
+// the kernel above were two uncoalesced L2 reads per output -- 42 us for 65 MB at config 2).  Q <= 1024.
+__global__ __launch_bounds__(256) void embed4_kernel(const float *__restrict__ cw, const int32_t *__restrict__ idx,
+                                                     int idx_stride, Act x0, int Q, int T) {
+  __shared__ float tab[2 * 1024];
+  const int c = blockIdx.y, b = blockIdx.z, t = 4 * (blockIdx.x * 256 + threadIdx.x);
+  for (int i = threadIdx.x; i < 2 * Q; i += 256) tab[i] = cw[(size_t)c * Q * 2 + i];
+  __syncthreads();
+  if (t >= T) return;
+  const int32_t *ib = idx + (size_t)b * idx_stride;
+  int qv[5];
+#pragma unroll
+  for (int e = 0; e < 5; ++e) {
+    const int u = t - 1 + e;
+    qv[e] = (u >= 0 && u < T) ? min(max(ib[u], 0), Q - 1) : -1;
+  }
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] = qv[e + 1] >= 0 ? tab[2 * qv[e + 1] + 1] : 0.f;
+    if (qv[e] >= 0) v[e] += tab[2 * qv[e]];
+  }
+  float *dst = x0.at(b, c, t);
+  if (t + 3 < T) {
+    *(f4 *)dst = f4{v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t + e < T) dst[e] = v[e];
+  }
+}
+
 // Gradient of the causal conv on a one-hot input = a scatter-add of dx0 columns into the two
 // embedding tables (tap 1 at class idx[t], tap 0 at idx[t-1]).  A workgroup owns `cg` channels
 // and EG_CHUNK time steps of one sequence and accumulates them in an LDS copy of its table
@@ -1027,7 +1059,11 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     c0.x0 = x0;
     launch_gemm_staged(c0, C, batch, s);
   } else {
-    hipLaunchKernelGGL(embed_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, p->causal_w,
+    if (Q <= 1024)
+      hipLaunchKernelGGL(embed4_kernel, dim3((T + 1023) / 1024, C, batch), dim3(256), 0, s, p->causal_w, index, index_stride,
+                         x0, Q, T);
+    else
+      hipLaunchKernelGGL(embed_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, p->causal_w,
                        index, index_stride, x0, C, Q, T);
   }
   Act zv = act_view(buf->z, batch, C, g.Tp);
