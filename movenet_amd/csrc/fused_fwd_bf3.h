@@ -401,8 +401,13 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
 // gone.  The layer's LDS image (W1 in fp32 MFMA order, W2 as planes, the four bias vectors) is written once per
 // forward call by fsc_pack_kernel and copied linearly (the staging loops of the fp32 kernel: ~8 us per launch).
 // ----------------------------------------------------------------------------------------
-constexpr int FSC_W1_BYTES = 4 * 24 * 1024;                                  // [4 blocks][24 k-step groups][64 lanes][4] floats
-constexpr int FSC_LDS_BYTES = FSC_W1_BYTES + FS3_W2_BYTES + 256 * 4, FSC_PACK_F = FSC_LDS_BYTES / 4;
+// LDS image (exactly the CU's 160 KB): the x(t - d) block of W1 as planes (48 KB: it too on the bf16 matrix cores), the
+// x(t) and context blocks as fp32 MFMA operands (64 KB), W2 as planes (48 KB).  The four bias vectors do not fit any
+// more: each lives in ONE register (lane i holds element i) and is read by ds_bpermute where the LDS copy was read.
+constexpr int FSC_XD_BYTES = 4 * 4 * 3 * 1024;                               // [4 blocks][4 k-steps][3 planes][64 lanes][8 bf16]
+constexpr int FSC_W1_BYTES = 4 * 16 * 1024;                                  // [4 blocks][16 k-step groups][64 lanes][4] floats
+constexpr int FSC_LDS_BYTES = FSC_XD_BYTES + FSC_W1_BYTES + FS3_W2_BYTES, FSC_PACK_F = FSC_LDS_BYTES / 4;
+static_assert(FSC_LDS_BYTES == 160 * 1024, "the conditioned layer's image fills a CU's LDS");
 struct FscPackArgs {
   const float *wf[FS3_PACK_LAYERS], *wg[FS3_PACK_LAYERS], *wr[FS3_PACK_LAYERS], *ws[FS3_PACK_LAYERS];
   const float *br[FS3_PACK_LAYERS], *bs[FS3_PACK_LAYERS];
@@ -410,21 +415,32 @@ struct FscPackArgs {
 };
 __global__ __launch_bounds__(256) void fsc_pack_kernel(FscPackArgs p, float *dst) {
   const int l = blockIdx.y, tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
-  float *W1 = dst + (size_t)l * FSC_PACK_F;
-  unsigned short *W2 = (unsigned short *)((unsigned char *)W1 + FSC_W1_BYTES);
-  float *BI = (float *)((unsigned char *)W1 + FSC_W1_BYTES + FS3_W2_BYTES);
-  constexpr int NK1 = 24;
-  for (int sI = tid; sI < 2 * 8192; sI += nthreads) {  // filter | gate, source (out, in, tap): as fused_layer64s_kernel
+  unsigned char *img = (unsigned char *)(dst + (size_t)l * FSC_PACK_F);
+  unsigned short *XD = (unsigned short *)img;
+  float *W1 = (float *)(img + FSC_XD_BYTES);
+  unsigned short *W2 = (unsigned short *)(img + FSC_XD_BYTES + FSC_W1_BYTES);
+  constexpr int NK1 = 16;
+  for (int sI = tid; sI < 2 * 8192; sI += nthreads) {  // filter | gate, source (out, in, tap)
     const int g = sI >> 13, r = sI & 8191;
     const int tap = r & 1, kc = (r >> 1) & 63, cm = r >> 7;
-    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3), kk = j + 32 * tap;
+    const int lhs = (kc >> 2) & 1, j = (kc & 3) + 4 * (kc >> 3);
     const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
-    W1[((blk * NK1 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? p.wg[l] : p.wf[l])[r];
+    const float w = (g ? p.wg[l] : p.wf[l])[r];
+    if (tap) {  // x(t): fp32 MFMA operand, k-step groups 0..7
+      W1[((blk * NK1 + (j >> 2)) * 64 + ln) * 4 + (j & 3)] = w;
+    } else {    // x(t - d): three planes, k-step j >> 3
+      unsigned short h, m, lo;
+      bf3_split1(w, h, m, lo);
+      const int at = (((blk * 4 + (j >> 3)) * 3) * 64 + ln) * 8 + (j & 7);
+      XD[at] = h;
+      XD[at + 512] = m;
+      XD[at + 1024] = lo;
+    }
   }
-  for (int sI = tid; sI < 2 * 4096; sI += nthreads) {  // context convs, source (out, in)
+  for (int sI = tid; sI < 2 * 4096; sI += nthreads) {  // context convs, source (out, in): k-step groups 8..15
     const int g = sI >> 12, r = sI & 4095;
     const int kc = r & 63, cm = r >> 6;
-    const int lhs = (kc >> 2) & 1, kk = 64 + (kc & 3) + 4 * (kc >> 3);
+    const int lhs = (kc >> 2) & 1, kk = 32 + (kc & 3) + 4 * (kc >> 3);
     const int blk = 2 * g + (cm >> 5), ln = (cm & 31) + 32 * lhs;
     W1[((blk * NK1 + (kk >> 2)) * 64 + ln) * 4 + (kk & 3)] = (g ? p.wcg[l] : p.wcf[l])[r];
   }
@@ -440,15 +456,12 @@ __global__ __launch_bounds__(256) void fsc_pack_kernel(FscPackArgs p, float *dst
     W2[at + 512] = m;
     W2[at + 1024] = lo;
   }
-  for (int i = tid; i < 256; i += nthreads)
-    BI[i] = i < 64 ? p.br[l][i] : i < 128 ? p.bs[l][i - 64] : i < 192 ? p.bcf[l][i - 128] : p.bcg[l][i - 192];
 }
 
 __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPArgs a, int chunks_per_b, int chunk_t) {
   constexpr bool HAS_CTX = true;
-  constexpr int C = 64, NK1 = 24, W1_F = 4 * NK1 * 256;
+  constexpr int C = 64, NK1 = 16;
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
-  float *W1 = fs_lds, *BI = (float *)((unsigned char *)fs_lds + FSC_W1_BYTES + FS3_W2_BYTES);  // BI: br | bs | bcf | bcg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
@@ -478,9 +491,14 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
     }
   }
   __syncthreads();
-  const unsigned w1a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)W1 + 16u * lane;
+  const unsigned xda = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)fs_lds + 16u * lane;
+  const unsigned w1a = xda + (unsigned)FSC_XD_BYTES;
   unsigned w2a = w1a + (unsigned)FSC_W1_BYTES, w2b = w2a + 2u * 4u * 3072u;
   asm volatile("" : "+v"(w2a), "+v"(w2b));
+  // the bias vectors, one register each (lane i: element i), read with ds_bpermute
+  const int bv_r = __float_as_int(a.br[lane]), bv_s = __float_as_int(a.bs[lane]);
+  const int bv_cf = __float_as_int(a.bcf[lane]), bv_cg = __float_as_int(a.bcg[lane]);
+#define FSC_BIAS(vec_, ch_) __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (ch_), (vec_)))
   typedef float fsv4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) fsv4 lds_v4;
   // channel of accumulator register r of block h in this lane: 32 h + (r & 3) + 8 (r >> 2) + 4 lh
@@ -591,18 +609,27 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // x(t) (prefetched: consumed first, fp32 MFMAs), x(t - d) (bf16 planes), context (fp32 MFMAs)
 #pragma unroll
     for (int kq = 0; kq < NK1; ++kq) {
-      const int k4 = kq < 8 ? 8 + kq : kq < 16 ? kq - 8 : kq;  // x(t), x(t - d), context
+      if (kq == 8) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          u32x4 bh, bm, bl;
+          bf3_split8(&xa0[8 * ks], bh, bm, bl);
+#pragma unroll
+          for (int blk = 0; blk < 4; ++blk) bf3_mfma6(acc[blk], xda + 3072u * (unsigned)(blk * 4 + ks), bh, bm, bl);
+        }
+      }
       fsv4 aw[4];
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w1a + 4u * (unsigned)((blk * NK1 + k4) * 256));
+      for (int blk = 0; blk < 4; ++blk) aw[blk] = *(const lds_v4 *)(uintptr_t)(w1a + 4u * (unsigned)((blk * NK1 + kq) * 256));
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
-          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-              aw[blk][e], k4 >= 16 ? xn1[4 * (k4 - 16) + e] : k4 >= 8 ? xb1[4 * (k4 - 8) + e] : xa0[4 * k4 + e], acc[blk], 0, 0, 0);
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[blk][e], kq >= 8 ? xn1[4 * (kq - 8) + e] : xb1[4 * kq + e], acc[blk], 0, 0,
+                                                          0);
     }
     // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
     float z[32];
@@ -612,8 +639,8 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cg_ = 32 * h + (r & 3) + 8 * (r >> 2) + cbase;
-        const float tv = tanh_fast(HAS_CTX ? acc[h][r] + BI[128 + cg_] : acc[h][r]);
-        const float sv = sigmoid_fast(HAS_CTX ? acc[2 + h][r] + BI[192 + cg_] : acc[2 + h][r]);
+        const float tv = tanh_fast(acc[h][r] + FSC_BIAS(bv_cf, cg_));
+        const float sv = sigmoid_fast(acc[2 + h][r] + FSC_BIAS(bv_cg, cg_));
         z[16 * h + r] = tv * sv;
         const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tv), thb, oth, c0 * thld4, FS_AUX_SAVE);
@@ -672,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c0 = 32 * h + (r & 3) + 8 * (r >> 2);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[h][r] + BI[c0 + cbase]) + xb1[16 * h + r]), xob, oxo_m,
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[h][r] + FSC_BIAS(bv_r, c0 + cbase)) + xb1[16 * h + r]), xob, oxo_m,
                                                 c0 * xold4, 0);
         }
 #pragma unroll
@@ -680,7 +707,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int k0 = 32 * h + (r & 3) + 8 * (r >> 2);
-          const float v = acc[2 + h][r] + BI[64 + k0 + cbase];
+          const float v = acc[2 + h][r] + FSC_BIAS(bv_s, k0 + cbase);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a.first_layer ? v : xa0[16 * h + r] + v), skb, osk_m, k0 * skld4, 0);
         }
     }
