@@ -284,6 +284,16 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *params, const mvn_param
                  const mvn_fwd_buffers *fwd, const mvn_bwd_buffers *bwd, const float *out,
                  const float *dout, int normalize, int remove_last, void *stream);
 
+/* Diagnostic: which form the layer loop of the process's last mvn_backward took -- 0 none yet,
+ * 1 the generic two-kernel forms (any dims), 2 the two fused halves per layer (C = K = 64,
+ * csrc/fused_bwd.h), 3 ONE kernel per layer with the input gradient in scatter form
+ * (csrc/fused_bwd_l.h, the default at C = K = 64).  Tests assert on it so that a silent
+ * fall-back to a slower form cannot pass for the fast one. */
+#define MVN_BWD_FORM_GENERIC 1
+#define MVN_BWD_FORM_HALVES 2
+#define MVN_BWD_FORM_ONE 3
+int mvn_last_backward_form(void);
+
 /* ------------------------------------------------------------------------
  * Local conditioning: video encoder + learned upsampler (movenet/wavenet.py:94-118,
  * :149-156).  video (B, F, 64, 64, Cin) fp32 -> Conv3d(k=(1,64,64)) -> (B, C, F)

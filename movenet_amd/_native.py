@@ -23,6 +23,7 @@ MVN_ERR_LAUNCH = -4
 MVN_ERR_UNSUPPORTED = -5
 
 GEN_AUTO, GEN_GENERIC, GEN_STREAM, GEN_PIPE, GEN_PIPE_F16, GEN_FOLD = 0, 1, 2, 3, 4, 5
+BWD_FORM_GENERIC, BWD_FORM_HALVES, BWD_FORM_ONE = 1, 2, 3  # mvn_last_backward_form (include/movenet_hip.h)
 PIPE_VARIANTS = (GEN_PIPE, GEN_PIPE_F16, GEN_FOLD)  # variants with a hand-off status word
 
 
@@ -118,6 +119,7 @@ SIGNATURES = {
                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FwdBuffers),
                                C.POINTER(BwdBuffers), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                C.c_void_p]),
+    "mvn_last_backward_form": (C.c_int, []),
     "mvn_upsample_video": (C.c_int, [C.POINTER(Dims), C.POINTER(VideoParams), C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p]),

@@ -10,6 +10,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned bf3_top(float x) { return __float_as_uint(x) & 0xffff0000u; }
 
+// (the two residuals of a pair as ONE packed subtraction: where the vector ALU is what a kernel waits for -- the fused
+// layer backward -- a split of eight is 36 instructions instead of 44)
+typedef float bf3_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned bf3_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf3_f2 bf3_pk_sub(bf3_f2 a, bf3_f2 b) {
+  bf3_f2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // three bf16 planes of 8 fp32 values, element e of a plane = value e (two per register, low half first)
 __device__ __forceinline__ void bf3_split8(const float *x, u32x4 &h, u32x4 &m, u32x4 &l) {
 #pragma unroll
@@ -22,6 +32,20 @@ __device__ __forceinline__ void bf3_split8(const float *x, u32x4 &h, u32x4 &m, u
     h[i] = __builtin_amdgcn_perm(bh, ah, 0x07060302);  // {top16(b), top16(a)}
     m[i] = __builtin_amdgcn_perm(bm, am, 0x07060302);
     l[i] = __builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302);
+  }
+}
+// the same planes with the two residuals of a pair as ONE packed subtraction each (36 instructions instead of 44)
+__device__ __forceinline__ void bf3_split8p(const float *x, u32x4 &h, u32x4 &m, u32x4 &l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf3_f2 v = {x[2 * i], x[2 * i + 1]};
+    const bf3_u2 vh = __builtin_bit_cast(bf3_u2, v) & 0xffff0000u;
+    const bf3_f2 r = bf3_pk_sub(v, __builtin_bit_cast(bf3_f2, vh));          // exact
+    const bf3_u2 rm = __builtin_bit_cast(bf3_u2, r) & 0xffff0000u;
+    const bf3_f2 r2 = bf3_pk_sub(r, __builtin_bit_cast(bf3_f2, rm));         // exact
+    h[i] = __builtin_amdgcn_perm(vh.y, vh.x, 0x07060302);
+    m[i] = __builtin_amdgcn_perm(rm.y, rm.x, 0x07060302);
+    l[i] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302);
   }
 }
 
@@ -51,8 +75,12 @@ __device__ __forceinline__ void bf3_split1(float w, unsigned short &h, unsigned 
 // acc += A x B for one 32 x 32 x 16 block, both operands as planes in registers: smallest terms first
 __device__ __forceinline__ void bf3_mfma6r(f32x16 &acc, const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
                                            const u32x4 &bm, const u32x4 &bl) {
+#if defined(MVN_EXP) && MVN_EXP == 74  // (timing build: no MFMAs)
+#define BF3_MFR(a_, b_) acc[0] += __uint_as_float(a_[0] ^ b_[0])
+#else
 #define BF3_MFR(a_, b_) \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc, 0, 0, 0)
+#endif
   BF3_MFR(al, bh);
   BF3_MFR(ah, bl);
   BF3_MFR(am, bm);

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libmovenet_hip.so")
 STAMP = os.path.join(LIB_DIR, "libmovenet_hip.stamp")
 
 SOURCES = ["common.hip", "generate.hip", "generate_pipe.hip", "generate_pipe_h16.hip", "generate_fold.hip", "sequence.hip", "video.hip", "trainer.hip"]
-HEADERS = ["common.h", "gen_common.h", "pipe_common.h", "gemm_family.h", "fused_layer.h", "fused_bwd.h", "fused_fwd.h", "fused_fwd_bf3.h", "bf3.h", os.path.join(ROOT, "include", "movenet_hip.h")]
+HEADERS = ["common.h", "gen_common.h", "pipe_common.h", "gemm_family.h", "fused_layer.h", "fused_bwd.h", "fused_bwd_l.h", "fused_fwd.h", "fused_fwd_bf3.h", "bf3.h", os.path.join(ROOT, "include", "movenet_hip.h")]
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",

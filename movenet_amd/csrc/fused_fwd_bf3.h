@@ -32,7 +32,7 @@ __device__ __forceinline__ void bf3_mfma6(f32x16 &acc, unsigned wa, const u32x4 
   const u32x4 ah = *(const lds_u4 *)(uintptr_t)wa;
   const u32x4 am = *(const lds_u4 *)(uintptr_t)(wa + 1024u);
   const u32x4 al = *(const lds_u4 *)(uintptr_t)(wa + 2048u);
-#if MVN_EXP == 25
+#if MVN_EXP == 25 || MVN_EXP == 74
 #define BF3_MF(a_, b_) acc[0] += __uint_as_float(a_[0] ^ b_[0])
 #else
 #define BF3_MF(a_, b_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc, 0, 0, 0)

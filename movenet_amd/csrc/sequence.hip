@@ -30,6 +30,7 @@
 #include "fused_bwd.h"
 #include "fused_fwd.h"
 #include "fused_fwd_bf3.h"
+#include "fused_bwd_l.h"
 
 namespace mvn {
 
@@ -1271,6 +1272,9 @@ int mvn_forward_f16(const mvn_dims *dims, const mvn_params *p, const int32_t *in
                       true);
 }
 
+static int g_last_bwd_form = 0;  // (process-wide: autograd runs the backward on a thread of its own)
+int mvn_last_backward_form(void) { return g_last_bwd_form; }
+
 int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grads *gr,
                  const int32_t *index, int index_stride, int batch, int t_len,
                  const mvn_fwd_buffers *fwd, const mvn_bwd_buffers *bwd, const float *out,
@@ -1478,7 +1482,100 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   auto await = [&](int e, hipStream_t on) {
     if (fork) (void)hipStreamWaitEvent(on, side->ev[e], 0);
   };
-  for (int l = g.L - 1; l >= 0; --l) {
+  // r4: the layer's backward as ONE kernel, input gradients in scatter form (fused_bwd_l.h): df | dg stays on chip.
+  // Two pairs (A', P0) of (B, C, Tp) tensors alternate between the layers: dx_a | dx_b and -- audio only -- the two
+  // row halves of the dfg tensor, which nothing else uses then; conditioned layers still write dfg for the context
+  // pass, their second pair lives in dlogit (dead behind the head's backward) when it is large enough.
+  // MOVENET_HIP_BWD_FORM=split keeps the two-half form of r2 / r3 (cross-checks, A/B); read per call.
+  Act spair[2][2];
+  bool scatter = false;
+  // (tensors too small for the reservation above -- the parity tests' smallest -- get a bias region sized for
+  // the workgroups that fit: the plan takes fewer, longer chunks then)
+  float *sc_bias = bias_scratch2, *sc_slab = slab;
+  size_t sc_bias_floats = bias2_floats, sc_slab_floats = slab_floats;
+  if (!sc_bias && !has_ctx && slab) {
+    const size_t total = (size_t)batch * Q * g.Sp, n_fit = total / (128 * 64 + 128 * 128 + 128);
+    if (n_fit >= (size_t)batch) {
+      sc_bias_floats = n_fit * 128;
+      sc_slab_floats = total - sc_bias_floats;
+      sc_bias = bwd->da1 + sc_slab_floats;
+    }
+  }
+  if (all_fused && sc_bias && g.L < 4095 && g.Tp <= (1 << 21) && [] {
+        const char *e = getenv("MOVENET_HIP_BWD_FORM");
+        return !(e && e[0] == 's');
+      }()) {
+    spair[0][0] = act_view(bwd->dx_a, batch, C, g.Tp);
+    spair[0][1] = act_view(bwd->dx_b, batch, C, g.Tp);
+    bool have = true;
+    if (!has_ctx) {
+      spair[1][0] = Act{bwd->dfg, (long long)2 * C * g.Tp, g.Tp};
+      spair[1][1] = Act{bwd->dfg + (size_t)C * g.Tp, (long long)2 * C * g.Tp, g.Tp};
+    } else if (2 * g.act <= g.hid) {
+      spair[1][0] = act_view(bwd->dlogit, batch, C, g.Tp);
+      spair[1][1] = act_view(bwd->dlogit + (size_t)g.act, batch, C, g.Tp);
+    } else {
+      have = false;
+    }
+    FusedBwdLPlan pl0;
+    int cc = 0, cct = 0;
+    scatter = have && bwd_layer64_plan(A_lo[1], T, batch, sc_bias, sc_bias_floats, sc_slab, sc_slab_floats, &pl0) &&
+              (!has_ctx || bwd_dctx_wgctx64_fits(A_lo[1], T, batch, bias_scratch2, bias2_floats, slab, slab_floats, &cc, &cct));
+  }
+  g_last_bwd_form = scatter ? MVN_BWD_FORM_ONE : MVN_BWD_FORM_GENERIC;
+  if (scatter) {
+    int po = 1 ^ ((g.L - 1) & 1);  // (so that layer 0 writes pair 1 and the dense dx0 can go to dx_a)
+    for (int l = g.L - 1; l >= 0; --l) {
+      const int t_lo = A_lo[l + 1];
+      FusedBwdLArgs fa;
+      fa.t_lo = t_lo; fa.t_end = T; fa.d = dilation_of(dims, l); fa.t_skip0 = t_skip0; fa.t_base = g.t_base;
+      fa.up_lo = l + 1 < g.L ? A_lo[l + 2] : 0;
+      fa.up_d = l + 1 < g.L ? dilation_of(dims, l + 1) : 0;
+      fa.wr = p->residual_w[l]; fa.ws = p->skip_w[l]; fa.wf = p->filter_w[l]; fa.wg = p->gate_w[l];
+      fa.ga = spair[po ^ 1][0]; fa.gp = spair[po ^ 1][1];
+      if (l == g.L - 1) fa.ga.p = nullptr;  // the last layer's residual output is unused: no dxo
+      fa.dskip = dskip;
+      fa.th = act_view(fwd->th + (size_t)l * g.act, batch, C, g.Tp);
+      fa.sg = act_view(fwd->sg + (size_t)l * g.act, batch, C, g.Tp);
+      fa.xin = act_view(fwd->acts + (size_t)l * g.act, batch, C, g.Tp);
+      fa.oa = spair[po][0]; fa.op = spair[po][1];
+      fa.dfg = has_ctx ? dfg : Act{nullptr, 0, 0};
+      WgRsOp wr;
+      wr.t_begin = t_lo; wr.t_end = T; wr.C = C; wr.Kc = Kc; wr.t_skip0 = t_skip0; wr.t_base = g.t_base;
+      wr.dxo = fa.ga; wr.dskip = dskip; wr.th = fa.th; wr.sg = fa.sg;
+      wr.dwr = gr->residual_w[l]; wr.dbr = gr->residual_b[l]; wr.dws = gr->skip_w[l]; wr.dbs = gr->skip_b[l];
+      WgFgOpT<false> wf;
+      wf.t_begin = t_lo; wf.t_end = T; wf.C = C; wf.d = fa.d; wf.dfg = dfg; wf.xin = fa.xin; wf.ctx = ctxv;
+      wf.dwf = gr->filter_w[l]; wf.dwg = gr->gate_w[l];
+      wf.dwcf = nullptr; wf.dwcg = nullptr; wf.dbcf = nullptr; wf.dbcg = nullptr;
+      FusedBwdLPlan pl;
+      if (!bwd_layer64_plan(t_lo, T, batch, sc_bias, sc_bias_floats, sc_slab, sc_slab_floats, &pl)) {
+        set_error("mvn_backward: the fused layer backward lost its scratch at layer %d", l);
+        return MVN_ERR_BAD_ARG;
+      }
+      rc = launch_bwd_layer64(fa, wr, wf, batch, pl, s);
+      if (rc) return rc;
+      if (has_ctx) {  // (behind the layer's reduce: the slab scratch is free again)
+        int c_chunks = 0, c_chunk_t = 0;
+        if (!bwd_dctx_wgctx64_fits(t_lo, T, batch, bias_scratch2, bias2_floats, slab, slab_floats, &c_chunks, &c_chunk_t)) {
+          set_error("mvn_backward: the context pass lost its scratch at layer %d", l);
+          return MVN_ERR_BAD_ARG;
+        }
+        FusedBwdCArgs fc;
+        fc.t_begin = t_lo; fc.t_end = T; fc.wcf = p->ctx_filter_w[l]; fc.wcg = p->ctx_gate_w[l];
+        fc.dfg = dfg; fc.ctx = ctxv; fc.dctx = dctxv;
+        WgCtxOp co;
+        co.dwcf = gr->ctx_filter_w[l]; co.dwcg = gr->ctx_gate_w[l]; co.dbcf = gr->ctx_filter_b[l]; co.dbcg = gr->ctx_gate_b[l];
+        launch_bwd_dctx_wgctx64(fc, co, batch, bias_scratch2, slab, c_chunks, c_chunk_t, s);
+      }
+      po ^= 1;
+    }
+    // the first layer's input gradient in dense form for the embedding / causal-conv gradient below
+    hipLaunchKernelGGL(bwd_scatter_combine_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, s, spair[po ^ 1][0],
+                       spair[po ^ 1][1], spair[0][0], C, A_lo[1], dilation_of(dims, 0), T);
+    dxo_p = bwd->dx_a;
+  }
+  for (int l = scatter ? -1 : g.L - 1; l >= 0; --l) {
     const int d = dilation_of(dims, l);
     const int t_lo = A_lo[l + 1];
     Act th = act_view(fwd->th + (size_t)l * g.act, batch, C, g.Tp);
@@ -1547,6 +1644,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       if (rc) return rc;
     }
     flush_pending_rs(pend, s);  // (only if the second half did not take it along)
+    if (fused_a && fused_b) g_last_bwd_form = MVN_BWD_FORM_HALVES;
     const bool ctx_done = fused_c && fused_b;
     if (ctx_done) {  // (behind the layer's reduce: the slab scratch is free again)
       FusedBwdCArgs fc;

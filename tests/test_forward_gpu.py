@@ -228,8 +228,9 @@ def test_cross_entropy_on_probs_matches_torch_autograd():
 
 @pytest.mark.parametrize("layers,t_len,batch", [((3, 2), 100, 3), ((10, 1), 1024 + 700 + 37, 2), ((6, 2), 64 * 9 + 1, 1)])
 def test_fused_backward_kernels_match_two_kernel_forms_and_oracle(monkeypatch, layers, t_len, batch):
-    """C = K = 64 takes the fused backward (csrc/fused_bwd.h: dz + residual/skip weight
-    gradients, then dx + filter/gate weight gradients).  Ragged lengths put t_lo, t_skip0 and
+    """C = K = 64 takes the fused backward (r4: csrc/fused_bwd_l.h, ONE kernel per layer with the input
+    gradient in scatter form; before: csrc/fused_bwd.h, dz + residual/skip weight gradients, then dx +
+    filter/gate weight gradients).  Ragged lengths put t_lo, t_skip0 and
     T inside tiles and leave chunks with a single short tile; the last layer has no dxo.
     Checked against the two-kernel forms (MOVENET_HIP_NO_FUSED_BACKWARD=1, same process) and,
     where the oracle finishes in seconds, against torch autograd on the oracle."""
@@ -244,21 +245,33 @@ def test_fused_backward_kernels_match_two_kernel_forms_and_oracle(monkeypatch, l
     w = torch.linspace(0.5, 1.5, 256).view(1, 256, 1)
     monkeypatch.setenv("MOVENET_DEBUG_GUARD", "1")  # guard bands behind the backward pass's scratch tensors (ops.py)
 
-    def grads(no_fused):
-        if no_fused:
+    def grads(form):
+        # "one": the layer's backward as ONE kernel, input gradients in scatter form (csrc/fused_bwd_l.h, the default);
+        # "split": the two fused halves of r2 / r3 (csrc/fused_bwd.h); "plain": the two-kernel forms
+        monkeypatch.delenv("MOVENET_HIP_NO_FUSED_BACKWARD", raising=False)
+        monkeypatch.delenv("MOVENET_HIP_BWD_FORM", raising=False)
+        if form == "plain":
             monkeypatch.setenv("MOVENET_HIP_NO_FUSED_BACKWARD", "1")
-        else:
-            monkeypatch.delenv("MOVENET_HIP_NO_FUSED_BACKWARD", raising=False)
+        elif form == "split":
+            monkeypatch.setenv("MOVENET_HIP_BWD_FORM", "split")
         m = _model(cfg, sd).train()
         out = m(x.to(DEV), output_unnormalized=False)
         (out * w.to(DEV)).square().mean().backward()
+        monkeypatch.delenv("MOVENET_HIP_NO_FUSED_BACKWARD", raising=False)
+        monkeypatch.delenv("MOVENET_HIP_BWD_FORM", raising=False)
+        from movenet_amd import _native as N
+        # (a silent fall-back to a slower form must not pass for the form under test)
+        # ("split" falls to the generic kernels where its per-chunk slabs do not fit these small tensors' scratch)
+        assert N.lib().mvn_last_backward_form() in {"one": (N.BWD_FORM_ONE,), "split": (N.BWD_FORM_HALVES, N.BWD_FORM_GENERIC),
+                                                    "plain": (N.BWD_FORM_GENERIC,)}[form]
         return {k: (None if p.grad is None else p.grad.cpu()) for k, p in m.named_parameters()}
 
-    fused, plain = grads(False), grads(True)
-    for k in fused:
-        assert (fused[k] is None) == (plain[k] is None), k
-        if fused[k] is not None:
-            assert rel_err(fused[k], plain[k]) < 2e-5, k  # fp32 sums in another order
+    fused, split, plain = grads("one"), grads("split"), grads("plain")
+    for other in (split, plain):
+        for k in fused:
+            assert (fused[k] is None) == (other[k] is None), k
+            if fused[k] is not None:
+                assert rel_err(fused[k], other[k]) < 2e-5, k  # fp32 sums in another order
     if t_len <= 700:
         params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         out_o = O.forward(params, dims, x, output_unnormalized=False)
