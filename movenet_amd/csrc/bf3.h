@@ -10,16 +10,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned bf3_top(float x) { return __float_as_uint(x) & 0xffff0000u; }
 
-// (the two residuals of a pair as ONE packed subtraction: where the vector ALU is what a kernel waits for -- the fused
-// layer backward -- a split of eight is 36 instructions instead of 44)
-typedef float bf3_f2 __attribute__((ext_vector_type(2)));
-typedef unsigned bf3_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf3_f2 bf3_pk_sub(bf3_f2 a, bf3_f2 b) {
-  bf3_f2 d;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-
 // three bf16 planes of 8 fp32 values, element e of a plane = value e (two per register, low half first)
 __device__ __forceinline__ void bf3_split8(const float *x, u32x4 &h, u32x4 &m, u32x4 &l) {
 #pragma unroll
@@ -34,21 +24,6 @@ __device__ __forceinline__ void bf3_split8(const float *x, u32x4 &h, u32x4 &m, u
     l[i] = __builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302);
   }
 }
-// the same planes with the two residuals of a pair as ONE packed subtraction each (36 instructions instead of 44)
-__device__ __forceinline__ void bf3_split8p(const float *x, u32x4 &h, u32x4 &m, u32x4 &l) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bf3_f2 v = {x[2 * i], x[2 * i + 1]};
-    const bf3_u2 vh = __builtin_bit_cast(bf3_u2, v) & 0xffff0000u;
-    const bf3_f2 r = bf3_pk_sub(v, __builtin_bit_cast(bf3_f2, vh));          // exact
-    const bf3_u2 rm = __builtin_bit_cast(bf3_u2, r) & 0xffff0000u;
-    const bf3_f2 r2 = bf3_pk_sub(r, __builtin_bit_cast(bf3_f2, rm));         // exact
-    h[i] = __builtin_amdgcn_perm(vh.y, vh.x, 0x07060302);
-    m[i] = __builtin_amdgcn_perm(rm.y, rm.x, 0x07060302);
-    l[i] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302);
-  }
-}
-
 // two values into register i of the three planes (a quarter of bf3_split8: the pipelined products below split
 // the NEXT k-step's operand a pair at a time between the MFMAs of the current one)
 __device__ __forceinline__ void bf3_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {

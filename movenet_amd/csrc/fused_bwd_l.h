@@ -15,17 +15,31 @@
 //
 // A 512-thread workgroup (one per CU) owns 64-column tiles; LDS: U (128 x 64: [dxo; dskip], later [x(t - d); x(t)]),
 // G (tanh | sigmoid, overwritten in place by df | dg), O ([dxo -> A'; P0]: the output staging tile), all fp32 with
-// pitch 68, and [Wr | Ws]^T as three bf16 planes (48 KB, the dz product's A operand).  Every product runs on the
-// bf16 matrix cores in the bf16 x 3 form (bf3.h):
-//   phase 1: waves 0-3 dz (one 32 c x 32 t block each, K = the tile's 128 rows read across rows, weights from LDS),
-//            waves 4-7 the residual / skip weight gradient (a 32-row block x both channel blocks each, K = time);
-//            the tile's x rows are in flight meanwhile and land in U behind the barrier;
-//   gate:    the dz owners turn tanh | sigmoid into df | dg in place;
-//   phase 2: as bwd_dx_wgfg64_kernel -- wave (tap, K half, channel block) forms both 32-step blocks of its tap's
-//            product with its 48 plane registers of W_tap, every wave owns two blocks of the filter / gate weight
-//            gradient; the next tile's loads are issued in parts between the steps; the K halves meet in O.
+// pitch 68, and [Wr | Ws]^T as three bf16 planes (48 KB, the dz product's A operand): 150 KB.  Every product runs on
+// the bf16 matrix cores in the bf16 x 3 form (bf3.h), each phase as an OPERAND PIPELINE -- the LDS reads of stage s + 1
+// are issued ahead of the split and the six MFMAs of stage s:
+//   phase 1 (12 stages per wave): wave (K half, t block, c block) forms its half of a 32 c x 32 t block of dz (K = 64
+//            of the tile's 128 rows, read across rows; weights from LDS) and ONE block of the residual / skip weight
+//            gradient (K = time); the tile's x rows are in flight meanwhile and land in U behind the barrier;
+//   gate:    the two K halves of a block meet through the idle P0 staging rows, each wave handing over the half of its
+//            partial sums the other one finishes: all eight waves turn tanh | sigmoid into df | dg in place;
+//   phase 2 (20 stages): as bwd_dx_wgfg64_kernel -- wave (tap, K half, channel block) forms both 32-step blocks of its
+//            tap's product with its 48 plane registers of W_tap, every wave owns two blocks of the filter / gate weight
+//            gradient; the next tile's loads are issued in parts between the stages; the K halves meet in O.
 // Five barriers per tile (the two halves had three each).  Slabs and bias partial sums leave in wgrad2's format;
 // reduce_layer64_kernel adds them up.
+//
+// Where its time goes (timing builds 71-74 and the stamps of build 76, config 2, same box, us per layer): 198-209 as built,
+// 190 without any global access, 130 without MFMAs -- an ON-CHIP time, and by the stamps a vector-issue time: a tile
+// costs 23.6 k cycles, 16.8 k of them in the two phases, where every stage is a split of eight values (44 vector
+// instructions) feeding six MFMAs and two waves share a SIMD's vector port (54.9 M vector instructions per launch =
+// 1900 per wave and tile, matrix pipe busy 36 %).  Measured on the way, none kept: the split's residuals as packed
+// subtractions (36 instructions instead of 44: 212.6 against 205.5 us -- a v_pk_add_f32 costs more than the two adds it
+// replaces); two wave roles (waves 0-3 the data path over full K with 96 plane registers of tap weights and no K halves
+// to meet, waves 4-7 both weight gradients as 2 x 2 blocks: 52 splits per SIMD and tile instead of 64, four barriers
+// instead of five) -- 209 against 198 us: the prefetched tile no longer fits the register file and waits in scratch.
+// What would lift it is operands split ONCE into planes in LDS (88 wave-splits per tile instead of 256), which needs
+// 1.5 x the LDS per tile: 179 KB at this tile width.
 #pragma once
 #include "fused_bwd.h"
 #include "fused_fwd.h"
@@ -45,26 +59,12 @@ struct FusedBwdLArgs {
   Act dfg;                 // conditioned layers: df | dg written for the context pass (bwd_dctx_wgctx64_kernel)
 };
 
-#ifndef FBL_OPERAND_PIPE
-#define FBL_OPERAND_PIPE (MVN_EXP != 75)  // (timing build 75: the products as plain loops, right results)
-#endif
 constexpr int FBL_TILE_F = 128 * W2_LD;                 // floats per LDS tile
 constexpr int FBL_WIMG_BYTES = 2 * 8 * 3 * 1024;        // [c block][k-step][plane][lane][8 bf16]
 constexpr int FBL_LDS_BYTES = 3 * FBL_TILE_F * 4 + FBL_WIMG_BYTES;  // 150 KB
 
 __device__ __forceinline__ f4 f4_add(const f4 &x, const f4 &y) { return f4{x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w}; }
 
-// (measured, same box: the residuals of a pair as ONE v_pk_add_f32 -- 36 instructions per split of eight instead of
-// 44 -- made the kernel SLOWER, 212.6 against 205.5 us per layer, phase 2 of a tile 13.2 k cycles against 10.9 k: a
-// packed fp32 instruction costs this chip more than the two it replaces.  Timing build 77 keeps it.)
-#ifndef FBL_PACKED_SPLIT
-#define FBL_PACKED_SPLIT (MVN_EXP == 77)
-#endif
-#if FBL_PACKED_SPLIT
-#define FBL_SPLIT8 bf3_split8p
-#else
-#define FBL_SPLIT8 bf3_split8
-#endif
 template <bool WRITE_DFG>
 __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, int chunks_per_b, int chunk_t,
                                                             float *__restrict__ rs_bias_part, float *__restrict__ rs_part,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
       const float *src = o < C ? a.wf : a.wg;
       wv[e] = src[((size_t)(o & (C - 1)) * C + 32 * wc + li) * 2 + (half ? 0 : 1)];
     }
-    FBL_SPLIT8(wv, wp[j][0], wp[j][1], wp[j][2]);
+    bf3_split8(wv, wp[j][0], wp[j][1], wp[j][2]);
   }
   const int wm = wave >> 1, wn = wave & 1;  // filter / gate weight gradient: rows [32 wm, +32), columns [64 wn, +64)
   f32x16 accw[2], accr;                     // accr: residual / skip weight gradient, block (rows [32 wm, +32), channels [32 wn, +32))
@@ -258,7 +258,6 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
     f32x16 accd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accd[r] = 0.f;
-#if FBL_OPERAND_PIPE
     {
       // ---- phase 1 as an operand pipeline of 12 stages: the LDS reads of stage s + 1 are issued before the split and
       // the six MFMAs of stage s (left to the scheduler, every split waited out a read issued right in front of it).
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
           for (int e = 0; e < 8; ++e) ob[sI & 1][e] *= sgv[e];
         }
         u32x4 h, m, l;
-        FBL_SPLIT8(ob[sI & 1], h, m, l);
+        bf3_split8(ob[sI & 1], h, m, l);
         if (sI < 4) {
           bf3_mfma6(accd, wa0 + 3072u * (unsigned)(cb1 * 8 + 4 * kh1 + sI), h, m, l);
         } else if (((sI - 4) & 1) == 0) {
@@ -306,35 +305,6 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#else
-    {
-      // ---- dz (32 c x 32 t), this wave's K half = [Wr | Ws]^T (A: planes in LDS) x [dxo; dskip] (B: read across the tile's rows)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int ks = 4 * kh1 + k4;
-        float rv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = U[16 * ks + 8 * lh + e][32 * tq1 + li];
-        u32x4 bh, bm, bl;
-        FBL_SPLIT8(rv, bh, bm, bl);
-        bf3_mfma6(accd, wa0 + 3072u * (unsigned)(cb1 * 8 + ks), bh, bm, bl);
-      }
-      // ---- residual / skip weight gradient: rows [32 wm, +32) of [dxo; dskip] x z^T (channels [32 wn, +32)), K = time
-#pragma unroll
-      for (int G = 0; G < TT / 16; ++G) {
-        const f4 a0 = *(const f4 *)&U[32 * wm + li][16 * G + 2 * h4], a1 = *(const f4 *)&U[32 * wm + li][16 * G + 2 * h4 + 4];
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        u32x4 ah, am, al;
-        FBL_SPLIT8(av, ah, am, al);
-        const f4 t0v = *(const f4 *)&Gt[32 * wn + li][16 * G + 2 * h4], t1v = *(const f4 *)&Gt[32 * wn + li][16 * G + 2 * h4 + 4];
-        const f4 s0v = *(const f4 *)&Gt[C + 32 * wn + li][16 * G + 2 * h4], s1v = *(const f4 *)&Gt[C + 32 * wn + li][16 * G + 2 * h4 + 4];
-        const float zv[8] = {t0v.x * s0v.x, t0v.y * s0v.y, t0v.z * s0v.z, t0v.w * s0v.w,
-                             t1v.x * s1v.x, t1v.y * s1v.y, t1v.z * s1v.z, t1v.w * s1v.w};
-        u32x4 zh, zm, zl;
-        FBL_SPLIT8(zv, zh, zm, zl);
-        bf3_mfma6r(accr, ah, am, al, zh, zm, zl);
-      }
-#endif
       // the two K halves of a block meet through the P0 staging rows, each wave handing over the HALF of its partial
       // sums the other one finishes (registers 8 (1 - kh1) .. +8), so that all eight waves share the gate derivative
 #pragma unroll
@@ -391,7 +361,6 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
     for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accd2[ub][r] = 0.f;
-#if FBL_OPERAND_PIPE
     {
       // an operand pipeline of 20 stages, five per 16 time steps: the weight gradient's row operand of dfg, its two x
       // operands (six MFMAs each), then this wave's k-step of the tap product for both 32-step blocks (operand read
@@ -420,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
         }
         __builtin_amdgcn_sched_barrier(0);
         u32x4 h, m, l;
-        FBL_SPLIT8(ob[sI & 1], h, m, l);
+        bf3_split8(ob[sI & 1], h, m, l);
         if (k == 0) {
           ah = h; am = m; al = l;
         } else if (k < 3) {
@@ -431,41 +400,6 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#else
-#pragma unroll
-    for (int G = 0; G < TT / 16; ++G) {
-      if (spread) {
-        gload_r_part(t0 + TT, G);
-        if (G == 3) gload_r_part(t0 + TT, 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const f4 a0 = *(const f4 *)&Gt[32 * wm + li][16 * G + 2 * h4], a1 = *(const f4 *)&Gt[32 * wm + li][16 * G + 2 * h4 + 4];
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        u32x4 ah, am, al;
-        FBL_SPLIT8(av, ah, am, al);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const f4 x0 = *(const f4 *)&U[64 * wn + 32 * ni + li][16 * G + 2 * h4];
-          const f4 x1 = *(const f4 *)&U[64 * wn + 32 * ni + li][16 * G + 2 * h4 + 4];
-          const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-          u32x4 bh, bm, bl;
-          FBL_SPLIT8(xv, bh, bm, bl);
-          bf3_mfma6r(accw[ni], ah, am, al, bh, bm, bl);
-        }
-      }
-#pragma unroll
-      for (int ub = 0; ub < 2; ++ub) {
-        float dv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dv[e] = Gt[64 * kh + 16 * G + 8 * lh + e][32 * ub + li];
-        u32x4 dh, dm, dl;
-        FBL_SPLIT8(dv, dh, dm, dl);
-        bf3_mfma6r(accd2[ub], dh, dm, dl, wp[G][0], wp[G][1], wp[G][2]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
     FBL_STAMP(3)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores
     // ---- the K halves meet in O: rows [0, 64) hold dxo (tap 1: A' = dxo + W1^T dfg), rows [64, 128) take P0
@@ -613,16 +547,12 @@ static int launch_bwd_layer64(const FusedBwdLArgs &a, const RsOp &rs, const FgOp
     set_error("bwd_layer64: the (B, ch, Tp) views must share one row pitch");
     return MVN_ERR_BAD_ARG;
   }
+  const int n = pl.chunks * batch;
   const void *fn = wd ? (const void *)bwd_layer64_kernel<true> : (const void *)bwd_layer64_kernel<false>;
   const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(bwd_layer64)");
   if (rc) return rc;
-  const int n = pl.chunks * batch;
-  if (wd)
-    hipLaunchKernelGGL(bwd_layer64_kernel<true>, dim3(n), dim3(512), FBL_LDS_BYTES, s, a, pl.chunks, pl.chunk_t, pl.bias,
-                       pl.rs, pl.fg);
-  else
-    hipLaunchKernelGGL(bwd_layer64_kernel<false>, dim3(n), dim3(512), FBL_LDS_BYTES, s, a, pl.chunks, pl.chunk_t, pl.bias,
-                       pl.rs, pl.fg);
+  void *args[] = {(void *)&a, (void *)&pl.chunks, (void *)&pl.chunk_t, (void *)&pl.bias, (void *)&pl.rs, (void *)&pl.fg};
+  if (check_hip(hipLaunchKernel(fn, dim3(n), dim3(512), args, FBL_LDS_BYTES, s), "bwd_layer64")) return MVN_ERR_LAUNCH;
   hipLaunchKernelGGL((reduce_layer64_kernel<RsOp, FgOp>), dim3(260 + 128 * 128 / 32), dim3(32 * RED_SEG), 0, s, rs, pl.rs,
                      pl.bias, n, fg, pl.fg, n);
   return MVN_OK;

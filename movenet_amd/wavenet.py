@@ -9,10 +9,10 @@ arithmetic runs in hand-written HIP kernels through the C ABI of
 ``include/movenet_hip.h``; tensors must live on an MI355X -- there is no CPU
 or PyTorch-op fallback.
 
-The sub-modules below exist to hold parameters under the reference's names
-(and to draw the same default initialisation in the same order, so that the
-same ``torch.manual_seed`` yields the same initial weights as the reference);
-their own ``forward`` is never used.
+The sub-modules (``movenet_amd.modules``: the reference's five block classes by name)
+hold the parameters under the reference's names and draw the same default
+initialisation in the same order, so that the same ``torch.manual_seed`` yields the
+same initial weights as the reference; their own ``forward`` is never used.
 """
 from __future__ import annotations
 
@@ -25,6 +25,8 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
+from .modules import CausalConv1d, DenseConv, ResidualConvStack
+from .types import AudioTensor, VideoTensor  # noqa: F401  (re-exported like movenet/wavenet.py:15)
 from .generation import (GroupedGenerator, HostWords, PipeHandoffTimeout, RingGenerator, _require_gpu,
                          _stream_ptr, auto_plan, max_pipe_batch)
 
@@ -40,39 +42,6 @@ def upsample_kernel_size_solver(in_size, out_size, stride=1, padding=0, output_p
     (the ConvTranspose1d length formula); same contract as movenet/wavenet.py:34-47."""
     span = out_size - 1 - output_padding - (in_size - 1) * stride + 2 * padding
     return (int(span / dilation + 1),)
-
-
-class _Named(nn.Module):
-    """Parameter holder: attribute name -> sub-module, nothing else."""
-
-    def __init__(self, **mods):
-        super().__init__()
-        for name, m in mods.items():
-            setattr(self, name, m)
-
-    def forward(self, *a, **k):  # pragma: no cover
-        raise RuntimeError("parameter holder; the arithmetic lives in the HIP kernels")
-
-
-class _Stack(_Named):
-    def __init__(self, layer_size: int, stack_size: int, C: int, K: int):
-        nn.Module.__init__(self)
-        self.layer_size, self.stack_size = layer_size, stack_size
-        self.conv_layers = nn.ModuleList([
-            _Named(
-                conv_filter=_Named(conv=nn.Conv1d(C, C, 2, dilation=d, bias=False)),
-                conv_gate=_Named(conv=nn.Conv1d(C, C, 2, dilation=d, bias=False)),
-                context_conv_filter=nn.Conv1d(C, C, 1),
-                context_conv_gate=nn.Conv1d(C, C, 1),
-                conv_residual=nn.Conv1d(C, C, 1),
-                conv_skip=nn.Conv1d(C, K, 1),
-            )
-            for d in self.dilations
-        ])
-
-    @property
-    def dilations(self) -> List[int]:
-        return [1 << i for _ in range(self.stack_size) for i in range(self.layer_size)]
 
 
 class WaveNet(nn.Module):
@@ -96,9 +65,9 @@ class WaveNet(nn.Module):
                                stride=UPSAMPLE_STRIDE)
             for a, b in zip(sizes[:-1], sizes[1:])
         ])
-        self.causal_conv = _Named(conv=nn.Conv1d(Q, C, 2, padding=1, bias=False))
-        self.residual_conv_stack = _Stack(layer_size, stack_size, C, K)
-        self.dense_conv = _Named(conv1=nn.Conv1d(K, Q, 1), conv2=nn.Conv1d(Q, Q, 1))
+        self.causal_conv = CausalConv1d(Q, C)
+        self.residual_conv_stack = ResidualConvStack(layer_size, stack_size, C, K)
+        self.dense_conv = DenseConv(K, Q)
 
         self._dims = N.make_dims(layer_size, stack_size, Q, C, K)
         self._gen_variant = N.GEN_AUTO

@@ -70,3 +70,36 @@ def test_reference_checkpoint_flavours_load(tmp_path):
     torch.save([1, 2, 3], tmp_path / "junk.pth")
     with pytest.raises(ValueError):
         load_state_dict_file(tmp_path / "junk.pth")
+
+
+def test_reference_block_and_type_names():
+    """movenet/modules.py:15-142 and movenet/types.py:4-5 by name: the five block classes (same constructor signatures,
+    same attribute / parameter names, parameter holders without arithmetic of their own) and the two layout aliases."""
+    import typing
+
+    from movenet_amd import modules as M
+    from movenet_amd import types as T
+    m = W.WaveNet(3, 2, 32, residual_channels=8, skip_channels=4)
+    assert isinstance(m.causal_conv, M.CausalConv1d) and isinstance(m.dense_conv, M.DenseConv)
+    assert isinstance(m.residual_conv_stack, M.ResidualConvStack)
+    layer = m.residual_conv_stack.conv_layers[4]
+    assert isinstance(layer, M.GatedResidualConv1d) and isinstance(layer.conv_filter, M.DilatedCausalConv1d)
+    assert layer.conv_filter.conv.dilation == (2,) and tuple(layer.conv_skip.weight.shape) == (4, 8, 1)
+    # the reference's positional / keyword signatures
+    c = M.CausalConv1d(32, 8, kernel_size=2, bias=False)
+    assert tuple(c.conv.weight.shape) == (8, 32, 2) and c.conv.padding == (1,) and c.conv.bias is None and c.kernel_size == 2
+    d = M.DilatedCausalConv1d(8, dilation=4, kernel_size=2, bias=False)
+    assert d.conv.dilation == (4,) and d.conv.padding == (0,)
+    g = M.GatedResidualConv1d(8, 4, 16)
+    assert [n for n, _ in g.named_children()] == ["conv_filter", "conv_gate", "context_conv_filter", "context_conv_gate",
+                                                  "conv_residual", "conv_skip"]
+    s = M.ResidualConvStack(3, 2, 8, 4)
+    assert s.dilations == [1, 2, 4, 1, 2, 4] and len(s.conv_layers) == 6
+    h = M.DenseConv(4, 32)
+    assert tuple(h.conv1.weight.shape) == (32, 4, 1) and tuple(h.conv2.weight.shape) == (32, 32, 1)
+    with pytest.raises(RuntimeError, match="holds parameters"):
+        h(torch.zeros(1, 4, 3))
+    # layout aliases: (batch, channels, frames) / (batch, frames, height, width, channels)
+    assert typing.get_args(T.AudioTensor) == (torch.Tensor, ("batch", "channels", "frames"))
+    assert typing.get_args(T.VideoTensor)[1] == ("batch", "frames", "height", "width", "channels")
+    assert W.AudioTensor is T.AudioTensor and W.VideoTensor is T.VideoTensor

@@ -220,6 +220,84 @@ def test_conditioned_gradient_layout_is_one_message_gloo(tmp_path):
         assert torch.allclose(g, (r[0]["local"][n] + r[1]["local"][n]) / 2, atol=1e-6), n
 
 
+def _config4_worker(rank: int, world: int, port: int, out_dir: str):
+    """BASELINE configs[3] (video-conditioned, global batch 64 = 8 clips per rank on 8 ranks) as far as a CPU can take
+    it: the REAL model's parameter set (30 layers, C = K = 64, Q = 256: 1 491 200 floats), every rank's shard of a
+    64-clip synthetic dataset, the per-rank input seeds of SURVEY 8d (1234 + rank / 4321 + rank), the conditioned
+    gradient layout as ONE flat span, two optimizer steps."""
+    import hashlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    import numpy as np
+    from movenet_amd.dataset import SyntheticLoader
+    from movenet_amd.ops import VIDEO_PARAMS, decoder_param_names
+    from movenet_amd.parallel import FlatGradSync, init_distributed
+    from movenet_amd.utils.weights import synthetic_indices
+    from movenet_amd.wavenet import WaveNet
+    r, w, _ = init_distributed("gloo", str(port))
+    assert (r, w) == (rank, world)
+    torch.manual_seed(50 + rank)  # different initial weights per rank on purpose: the broadcast must fix that
+    model = WaveNet(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
+    sync = FlatGradSync(model.parameters(), world)
+    sync.broadcast_parameters(0)
+    # the rank's shard: 8 of the 64 clips, one batch of 8 (config 3's per-GPU batch)
+    loader = SyntheticLoader("synthetic://clips=64,frames=2000,seed=1234", 256, batch_size=8, rank=rank, world_size=world,
+                             use_video=True)
+    batches = list(loader)
+    clip_ids = [int(f.rsplit("/", 1)[1]) for b in batches for f in b.filepaths]
+    assert len(batches) == 1 and tuple(batches[0].audio.shape) == (8, 256, 2000) and tuple(batches[0].video.shape) == (8, 2, 64, 64, 1)
+    # bench.py's synthetic inputs: seeds 1234 + rank (audio classes) and 4321 + rank (frames) differ by rank
+    audio_idx = synthetic_indices(8, 64, 256, 1234 + rank)
+    frames = np.random.default_rng(4321 + rank).random((2, 4), dtype=np.float32)
+    lookup = dict(model.named_parameters())
+    L = 30
+    names = decoder_param_names(L, with_context=True) + list(VIDEO_PARAMS)
+    assert sorted(names) == sorted(lookup)
+    last = f"residual_conv_stack.conv_layers.{L - 1}.conv_residual."
+    n_total = sum(lookup[n].numel() for n in names)
+    digests, sent, paths = [], [], []
+    for step in range(2):
+        flat = torch.zeros(n_total)  # what ops._run_backward + VideoGradSlot hand to autograd: one zero-filled buffer
+        gen = torch.Generator().manual_seed(1000 * step + 1234 + rank)
+        off = 0
+        for n in names:
+            p = lookup[n]
+            if not n.startswith(last):  # the last layer's residual conv gets no gradient: a zero gap
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                p.grad.copy_(torch.randn(p.shape, generator=gen) * 1e-2)
+            off += p.numel()
+        sent.append(sync.sync_gradients())
+        paths.append(sync.last_path)
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-0.1)
+        digests.append(hashlib.sha256(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy().tobytes()).hexdigest())
+    torch.save({"clips": clip_ids, "audio_sum": int(audio_idx.sum()), "frames_sum": float(frames.sum()), "n_total": n_total,
+                "sent": sent, "paths": paths, "digests": digests}, os.path.join(out_dir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_world_size_eight_gloo(tmp_path):
+    """BASELINE configs[3] without the hardware: 8 ranks, global batch 64 -> 8 clips per rank, disjoint shards whose
+    union is the dataset, rank-offset seeds, the conditioned gradient span = every parameter of the model as ONE
+    message on every rank, identical replicas after two steps.  Precedent: movenet/trainer.py:226-238 (DDP),
+    movenet/dataset.py:78-86 (DistributedSampler)."""
+    world, port = 8, _free_port()
+    mp.spawn(_config4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"w{i}.pt", weights_only=True) for i in range(world)]
+    shards = [set(x["clips"]) for x in r]
+    assert all(len(x["clips"]) == 8 == len(s) for x, s in zip(r, shards))
+    assert set().union(*shards) == set(range(64)) and sum(len(s) for s in shards) == 64   # a partition of the dataset
+    assert len({x["audio_sum"] for x in r}) == world and len({x["frames_sum"] for x in r}) == world  # per-rank inputs
+    for x in r:
+        assert x["n_total"] == 1491200 and x["sent"] == [1491200, 1491200] and x["paths"] == ["contiguous-span"] * 2
+        assert x["digests"] == r[0]["digests"]   # identical replicas after each step
+    assert r[0]["digests"][0] != r[0]["digests"][1]
+
+
 def test_contiguous_span_rejects_overlap_and_foreign_storage():
     from movenet_amd.parallel import contiguous_grad_span
     a, b = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))
