@@ -135,6 +135,13 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch);
  * rounds x the stages' service time there).  For cost models (generation.auto_plan). */
 int mvn_gen_launch_pipelines(const mvn_dims *dims, int variant, int batch);
 
+/* 1 when the pipelined generators (MVN_GEN_PIPE / _PIPE_F16 / _FOLD) of this process are launched with
+ * hipLaunchCooperativeKernel -- the default: the runtime guarantees the co-residency their hand-offs
+ * need -- 0 when with an ordinary launch: a profiler's tool library is attached (rocprofv3: the
+ * cooperative queue's tear-down crashes the process at exit under rocprofiler-sdk) or
+ * MOVENET_PIPE_COOPERATIVE_LAUNCH=0 asks for it.  Decided once per process. */
+int mvn_gen_launch_is_cooperative(void);
+
 /* Size in floats of the packed weight blob / of the generator state (dilation
  * queues, plus the PIPE variant's hand-off area when the dims allow PIPE). */
 size_t mvn_gen_weights_floats(const mvn_dims *dims, int variant);

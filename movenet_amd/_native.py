@@ -98,6 +98,7 @@ SIGNATURES = {
     "mvn_output_size": (C.c_int, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_variant": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_int]),
     "mvn_gen_launch_pipelines": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_int]),
+    "mvn_gen_launch_is_cooperative": (C.c_int, []),
     "mvn_gen_weights_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_state_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int]),
     "mvn_gen_status_offset": (C.c_size_t, [C.POINTER(Dims), C.c_int]),

@@ -807,6 +807,9 @@ int pipe_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand, siz
 
 }  // namespace mvn
 
+extern "C" int mvn_gen_launch_is_cooperative(void) { return mvn::pipe_cooperative_launch() ? 1 : 0; }
+
+
 #ifdef MVN_PIPE_STAMPS
 extern "C" int mvn_debug_read_stamps(unsigned long long *out, size_t n) {
   if (n > sizeof(mvn::g_stamps) / 8) n = sizeof(mvn::g_stamps) / 8;

@@ -966,7 +966,6 @@ int pipe_h16_launch(const GenArgs &a, const mvn_dims *d, int batch, float *hand,
   }
   void *kargs[] = {(void *)&args, (void *)&gran, (void *)&err, (void *)&NS, (void *)&nb, (void *)&nseq};
   return check_hip(hipLaunchKernel(fn, dim3(slots * 8), dim3(NT), kargs, (size_t)lds_bytes, s), "mvn_generate(pipe_f16)");
-  return check_hip(hipGetLastError(), "mvn_generate(pipe_f16)");
 }
 
 }  // namespace mvn

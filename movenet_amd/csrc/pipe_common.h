@@ -2,7 +2,9 @@
 // generate_pipe_h16.hip: fp16 operands, C = 128): the granule hand-off, cross-lane moves as
 // DPP, the gate, and the step-closing choice (double softmax, arg-max / inverse-CDF sample).
 #pragma once
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "gen_common.h"
@@ -16,20 +18,38 @@ constexpr int PIPE_XCD_CUS = 32;  // CUs per XCD: one workgroup (133 KB of LDS) 
 constexpr unsigned PIPE_SPIN_LIMIT = 1u << 23;
 constexpr int PIPE_MAX_GRAN = 256;
 
-// How the pipelined generators are launched.  Default: an ORDINARY launch.  Co-residency of a
-// pipeline's stages is checked on the host with the kernel's own occupancy arithmetic before
-// every launch, a stage that nevertheless starves raises the sticky status word within a bounded
-// spin and the caller reruns on a kernel without hand-offs.
-// MOVENET_PIPE_COOPERATIVE_LAUNCH=1 asks for hipLaunchCooperativeKernel instead (the runtime
-// then also refuses to run the grid beside another kernel of the process).  It is not the
-// default because the cooperative queue the HIP runtime creates for it is torn down at process
-// exit inside libhsa-runtime64 AFTER rocprofiler-sdk has finalised its queue interception:
-// every rocprofv3 run of a process that had made one cooperative launch ended in SIGSEGV at
-// exit (r3: stack resolved in profiles/r03_exit_crash.md; same step time either way).
+// How the pipelined generators are launched.  Default: hipLaunchCooperativeKernel -- the runtime then guarantees
+// what the hand-offs need, every stage of every pipeline co-resident (it refuses the launch otherwise, and does not
+// run the grid beside another kernel of the process).  With an ORDINARY launch that guarantee is only the host's
+// occupancy check: a second stream or process holding CUs starves a stage, which spins up to PIPE_SPIN_LIMIT polls
+// per wait before it raises the sticky status word and the caller reruns on a kernel without hand-offs
+// (worst case ~2.3 s per starved wait at ~0.28 us per poll with s_sleep).
+// The ordinary launch is taken in exactly two cases:
+//   * a profiler's tool library is attached to the process (rocprofv3 / rocprofiler-sdk / roctracer): the cooperative
+//     queue the HIP runtime creates is torn down at process exit inside libhsa-runtime64 AFTER rocprofiler-sdk has
+//     finalised its queue interception -- every rocprofv3 run of a process that had made one cooperative launch
+//     ended in SIGSEGV at exit (r3: stack resolved in profiles/r03_exit_crash.md; same step time either way);
+//   * MOVENET_PIPE_COOPERATIVE_LAUNCH=0 asks for it (=1 forces the cooperative form even under a profiler).
+inline bool pipe_profiler_attached() {
+  for (const char *v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "ROCP_METRICS"})
+    if (const char *e = getenv(v))
+      if (e[0]) return true;
+  if (const char *pre = getenv("LD_PRELOAD"))
+    if (strstr(pre, "rocprof") || strstr(pre, "roctracer")) return true;
+  bool found = false;
+  if (FILE *f = fopen("/proc/self/maps", "r")) {  // a tool library injected any other way
+    char line[512];
+    while (!found && fgets(line, sizeof line, f))
+      found = strstr(line, "librocprofiler-sdk-tool") || strstr(line, "librocprofiler64") || strstr(line, "libroctracer64");
+    fclose(f);
+  }
+  return found;
+}
 inline bool pipe_cooperative_launch() {
   static const bool on = [] {
     const char *e = getenv("MOVENET_PIPE_COOPERATIVE_LAUNCH");
-    return e && e[0] == '1';
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return !pipe_profiler_attached();
   }();
   return on;
 }

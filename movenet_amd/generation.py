@@ -6,6 +6,8 @@ Replaces the per-sample window loop of /root/reference/movenet/wavenet.py:217-23
 """
 from __future__ import annotations
 
+import threading
+
 import os
 from typing import Dict, Optional
 
@@ -48,32 +50,43 @@ class HostWords:
     step late)."""
     RING, MAXW = 16, 64
     _rings: dict = {}
+    _lock = threading.Lock()
 
     @classmethod
     def publish(cls, words: torch.Tensor):
         """``words``: 1-D device tensor of <= 64 int32 / float32 values (already computed or being
-        computed on the current stream).  Returns the token ``read`` takes."""
-        dev = words.device
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
-        ring = cls._rings.get(key)
-        if ring is None:
-            ring = cls._rings[key] = [torch.zeros(cls.RING, cls.MAXW + 1, dtype=torch.int32).pin_memory(), 0]
-        ring[1] += 1
-        seq = (ring[1] & 0x3FFFFFFF) or 1
-        slot = ring[0][ring[1] % cls.RING]
+        computed on the current stream).  Returns the token ``read`` takes.  Thread-safe; when the
+        ring wraps onto a slot whose token has not been read yet, that token is RESOLVED first (its
+        values are copied out of the slot into the token), so a 17th publish never overwrites
+        values somebody is still going to ask for."""
         n = int(words.numel())
         if not 1 <= n <= cls.MAXW or words.dtype not in (torch.int32, torch.float32) or not words.is_contiguous():
             raise ValueError("HostWords.publish: 1..64 contiguous int32 / float32 values")
-        with torch.cuda.device(dev):
-            N.check(N.lib().mvn_publish_words(words.data_ptr(), n, seq, slot.data_ptr(),
-                                              torch.cuda.current_stream(dev).cuda_stream), "mvn_publish_words")
-        return slot, n, seq, words  # (words kept alive until read)
+        dev = words.device
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        with cls._lock:
+            ring = cls._rings.get(key)
+            if ring is None:
+                ring = cls._rings[key] = [torch.zeros(cls.RING, cls.MAXW + 1, dtype=torch.int32).pin_memory(), 0,
+                                          [None] * cls.RING]
+            ring[1] += 1
+            seq = (ring[1] & 0x3FFFFFFF) or 1
+            at = ring[1] % cls.RING
+            slot = ring[0][at]
+            old = ring[2][at]
+            if old is not None and old[4][0] is None:  # outstanding: wait for it, keep its values in the token
+                old[4][0] = cls._wait(old)
+            token = (slot, n, seq, words, [None])  # (words kept alive until read; [4]: values once resolved)
+            ring[2][at] = token
+            with torch.cuda.device(dev):
+                N.check(N.lib().mvn_publish_words(words.data_ptr(), n, seq, slot.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "mvn_publish_words")
+        return token
 
     @staticmethod
-    def read(token, timeout_s: float = 30.0):
-        """The published values as a list of Python ints / floats (by the dtype of ``words``)."""
+    def _wait(token, timeout_s: float = 30.0):
         import time
-        slot, n, seq, words = token
+        slot, n, seq, words, _ = token
         t0 = time.perf_counter()
         spins = 0
         while int(slot[n]) != seq:
@@ -87,6 +100,14 @@ class HostWords:
                     return words.tolist()
         vals = slot[:n]
         return vals.tolist() if words.dtype == torch.int32 else vals.view(torch.float32).tolist()
+
+    @classmethod
+    def read(cls, token, timeout_s: float = 30.0):
+        """The published values as a list of Python ints / floats (by the dtype of ``words``)."""
+        with cls._lock:  # (against a publish that wraps onto this token's slot at the same moment)
+            if token[4][0] is None:
+                token[4][0] = cls._wait(token, timeout_s)
+        return token[4][0]
 
 
 def _stream_ptr(device: torch.device) -> int:

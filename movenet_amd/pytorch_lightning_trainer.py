@@ -269,7 +269,12 @@ class Trainer:
                     # norm is one reduction over that span (parameters without a gradient are
                     # zero-filled gaps), not one launch per parameter; and nothing here reads a
                     # value back -- the record is resolved a step later (flush_records)
-                    span = contiguous_grad_span(used) if (self.track_grad_norm or self.clip > 0) and used else None
+                    # (... only while the gaps really are zero: mvn_backward writes a gradient for EVERY decoder parameter
+                    # into the buffer and autograd merely withholds the view of a frozen one -- its slot is a gap with
+                    # data in it, which torch's clip_grad_norm_ and the reference do not count.  Then: per parameter.)
+                    all_trainable = all(p.requires_grad for p in model.model.parameters())
+                    span = (contiguous_grad_span(used)
+                            if (self.track_grad_norm or self.clip > 0) and used and all_trainable else None)
                     if self.track_grad_norm and used:
                         if span is not None:
                             rec["grad_norm_total"] = span.norm(self.track_grad_norm)

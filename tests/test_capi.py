@@ -113,3 +113,21 @@ def test_loss_kernels_argument_checks():
     assert lib.mvn_ce_on_probs_forward(None, None, 2, 64, 10, None, None, None) == N.MVN_ERR_BAD_ARG
     assert "mvn_ce_on_probs_forward" in N.last_error()
     assert lib.mvn_ce_on_probs_backward(None, None, 2, 64, 10, 1.0, None, None, None) == N.MVN_ERR_BAD_ARG
+
+
+def test_pipelined_launch_form_policy():
+    """The pipelined generators launch cooperatively unless a profiler's tool library is attached or the caller
+    opts out (csrc/pipe_common.h; decided once per process, so each case is a process of its own)."""
+    import subprocess
+    import sys
+    code = "from movenet_amd import _native as N; print(N.lib().mvn_gen_launch_is_cooperative())"
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("MOVENET_PIPE_COOPERATIVE_LAUNCH", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "LD_PRELOAD")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, want in (({}, "1"), ({"MOVENET_PIPE_COOPERATIVE_LAUNCH": "0"}, "0"),
+                        ({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"}, "0"),
+                        ({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so",
+                          "MOVENET_PIPE_COOPERATIVE_LAUNCH": "1"}, "1")):
+        out = subprocess.run([sys.executable, "-c", code], env={**base, **extra}, cwd=root, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want, (extra, out.stdout, out.stderr)

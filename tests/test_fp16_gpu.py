@@ -197,6 +197,32 @@ def test_fp16_pipelines_serve_several_sequences_in_turn():
             assert len(torch.unique(g.samples[:, rf:])) > 8
 
 
+def test_fp16_stage_forms_agree_over_a_queue_wrap():
+    """The fp16 generator runs THREE layers per stage (21 stages) when a pipeline serves one sequence (batch <= 8:
+    gen_pipe_h16_kernel<false, true>) and TWO (31 stages) when it serves several in turn (<true, true>), so batch 8 and
+    batch 9 run different kernels.  Teacher-forced over the same histories for 520 steps behind the prompt -- past the
+    wrap of the longest dilation queue (512) -- the two forms give the same logits (same per-layer arithmetic, another
+    partition into stages) and the same arg-max wherever the margin is clear."""
+    sd = make_state_dict(**CFG5, seed=6, gain=1.5, head_gain=6.0)
+    rf = O.Dims(**CFG5).receptive_fields
+    n_total = rf + 520
+    hist = synthetic_indices(9, n_total, 256, 21)
+    g8 = _gen(CFG5, sd, 8, n_total, N.GEN_PIPE_F16, temperature=0.0)
+    c8, l8 = g8.teacher_forced(hist[:8].to(DEV), logits_t0=rf)
+    g8.check_errors()
+    g9 = _gen(CFG5, sd, 9, n_total, N.GEN_PIPE_F16, temperature=0.0)
+    c9, l9 = g9.teacher_forced(hist.to(DEV), logits_t0=rf)
+    g9.check_errors()
+    l8, l9 = l8.cpu().numpy(), l9[:8].cpu().numpy()
+    rng = float(l8.max() - l8.min())
+    err = float(np.abs(l8 - l9).max()) / rng
+    assert err <= 0.1 * FP16_TOL, err   # (measured: see the assertion message if it ever moves)
+    top2 = np.sort(l8, axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 2 * FP16_TOL * rng
+    a8, a9 = l8.argmax(-1), l9.argmax(-1)
+    assert clear.mean() > 0.5 and np.array_equal(a8[clear], a9[clear])
+
+
 def test_fp16_capacity_one_xcd():
     """60 layers = 31 stages of two layers: one XCD per pipeline, eight pipelines per launch, up to
     eight sequences each (fp32: 61 stages over two XCDs, four sequences)."""

@@ -549,9 +549,12 @@ def test_pipe_status_word_is_sticky_and_checked(variant):
     assert torch.equal(g.samples, ref.samples)
 
 
-def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
+@pytest.mark.parametrize("B", [3, 20])
+def test_model_generate_reruns_on_pipe_timeout(monkeypatch, B):
     """WaveNet.generate never returns unchecked samples: with the PIPE status word raised
-    during the call it reruns the same call on STREAM in the same process."""
+    during the call it reruns the same call on STREAM in the same process.  B = 20 is a MULTI
+    launch (16 pipelines, the first four serving two sequences in turn): the starved path with
+    several sequences per pipeline."""
     from movenet_amd import generation as G
     from movenet_amd.utils.weights import make_state_dict
     from movenet_amd.wavenet import WaveNet
@@ -559,10 +562,11 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch):
     model = WaveNet(**CFG2)
     model.load_state_dict(sd, strict=False)
     model.to(DEV)
-    rf, B, n_new = 3072, 3, 20
+    rf, n_new = 3072, 20
     prompt = one_hot(synthetic_indices(B, rf, 256, 8), 256).to(DEV)
     want = model.generate(prompt, n_samples=rf + n_new, temperature=0.0)
     assert model.last_generate_fallback is None
+    assert N.lib().mvn_gen_launch_is_cooperative() == 1  # no profiler attached: the runtime guarantees co-residency
     real_advance, poked = G.RingGenerator.advance, []
 
     def advance(self, n):
