@@ -25,7 +25,7 @@ constexpr int PIPE_MAX_GRAN = 256;
 // per wait before it raises the sticky status word and the caller reruns on a kernel without hand-offs
 // (worst case ~2.3 s per starved wait at ~0.28 us per poll with s_sleep).
 // The ordinary launch is taken in exactly two cases:
-//   * a profiler's tool library is attached to the process (rocprofv3 / rocprofiler-sdk / roctracer): the cooperative
+//   * a profiler's tool library is attached to the process (rocprofv3 / rocprofiler-sdk tool, rocprof v1 / v2): the cooperative
 //     queue the HIP runtime creates is torn down at process exit inside libhsa-runtime64 AFTER rocprofiler-sdk has
 //     finalised its queue interception -- every rocprofv3 run of a process that had made one cooperative launch
 //     ended in SIGSEGV at exit (r3: stack resolved in profiles/r03_exit_crash.md; same step time either way);
@@ -35,12 +35,13 @@ inline bool pipe_profiler_attached() {
     if (const char *e = getenv(v))
       if (e[0]) return true;
   if (const char *pre = getenv("LD_PRELOAD"))
-    if (strstr(pre, "rocprof") || strstr(pre, "roctracer")) return true;
+    if (strstr(pre, "rocprof")) return true;
   bool found = false;
   if (FILE *f = fopen("/proc/self/maps", "r")) {  // a tool library injected any other way
     char line[512];
     while (!found && fgets(line, sizeof line, f))
-      found = strstr(line, "librocprofiler-sdk-tool") || strstr(line, "librocprofiler64") || strstr(line, "libroctracer64");
+      // (not libroctracer64 / librocprofiler-register: every PyTorch process maps those)
+      found = strstr(line, "librocprofiler-sdk-tool") || strstr(line, "librocprofiler64");
     fclose(f);
   }
   return found;
