@@ -38,17 +38,61 @@ sys.path.insert(0, ROOT)
 CFG = dict(layer_size=10, stack_size=3, input_channels=256, residual_channels=64, skip_channels=64)
 BATCH = 16
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (vector)" = "Peak FP32 (matrix)"
-# HBM-side bytes per generated sample per sequence of gen_pipe_kernel<64>, from separate
-# rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an earlier run of this same command; NOT
-# measured by the run that prints the line (roofline.traffic_source says so)
-PMC_TRAFFIC = {
-    3: {"bytes_per_step_seq": (19818.3 + 15008.8) * 1024 / (16 * 16000),
-        "source": "profiles/r02_pmc_summary.json (gen_pipe_kernel<64>: FETCH_SIZE 19818 KiB + WRITE_SIZE "
-                  "15009 KiB per 16000-step launch of 16 sequences)"},
-    5: {"bytes_per_step_seq": (26321.9 + 17943.8) * 1024 / (16 * 16000),
-        "source": "profiles/r02_pmc_summary.json (gen_fold_kernel: FETCH_SIZE 26322 KiB + WRITE_SIZE "
-                  "17944 KiB per 16000-step launch of 16 sequences)"},
-}
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD)
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PROFILE_TAG = "r04"              # the round whose rocprofv3 passes the profiled figures below are read from
+
+
+def profiled(section: str, key: str = None):
+    """A figure of THIS round's counter passes (profiles/<tag>_pmc_summary.json, written by
+    scripts/profile_summary.py from scripts/profile_round.sh), or None when the file is not there: numbers that the
+    run printing the line cannot measure itself are quoted with their source file, never as its own."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f).get(section)
+        return d if key is None or d is None else d.get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def fold_stamps():
+    """Per-stage / hop / head times of the FOLD generator from the stamped build (scripts/pipe_stamps.py --fold --json),
+    tracked as profiles/<tag>_fold_stamps.json; None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_fold_stamps.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+def headline_traffic(variant_used: int, n_new: int):
+    """HBM-side bytes per launch of the generator kernel from THIS round's --pmc passes (profiles/), or None."""
+    name = {3: "gen_pipe_kernel", 5: "gen_fold_kernel"}.get(variant_used)
+    k = profiled("kernels") or {}
+    hit = next((v for kk, v in k.items() if name and kk.startswith(name) and v.get("FETCH_SIZE_KiB_as_reported") is not None), None)
+    if not hit:
+        return None
+    nbytes = (hit["FETCH_SIZE_KiB_as_reported"] + hit["WRITE_SIZE_KiB"]) * 1024.0
+    return {"bytes_per_launch": nbytes, "bytes_per_sample_per_sequence": nbytes / (BATCH * n_new),
+            "source": f"profiles/{PROFILE_TAG}_pmc_summary.json kernels.{name}* (FETCH_SIZE as reported + WRITE_SIZE, separate --pmc "
+                      f"passes of this command with {n_new}-step launches of {BATCH} sequences); NOT measured by this run",
+            "note": "far below the algorithmic 15,360 B per sample: the 12.6 MB of dilation queues stay in L2 / MALL"}
+
+
+def latency_floor(variant_used: int, us_per_step: float) -> dict:
+    """The step of the pipelined generator against ITS bound: the dependent chain of a sample -- stages x (chain + hop) +
+    head -- from the in-kernel stamps of the diagnostic build (profiles/<tag>_fold_stamps.json; the stamps build runs
+    ~8 % slower than the product, so the sum is scaled by product step / stamped step)."""
+    st = fold_stamps() if variant_used == 5 else None
+    if not st:
+        return {"latency_floor_us": None, "frac_of_latency_floor": None}
+    scale = st.get("product_over_stamped", 1.0)
+    floor = (sum(st["stage_chain_us"]) + sum(st["hop_us"]) + st["head_us"]) * scale
+    return {"latency_floor_us": floor, "frac_of_latency_floor": floor / us_per_step,
+            "latency_floor_parts": {"stages": len(st["stage_chain_us"]), "stage_chain_us_mean": sum(st["stage_chain_us"]) / len(st["stage_chain_us"]),
+                                    "hop_us_mean": sum(st["hop_us"]) / len(st["hop_us"]), "head_us": st["head_us"],
+                                    "stamped_step_us": st["step_us"], "scale_product_over_stamped": scale,
+                                    "source": f"profiles/{PROFILE_TAG}_fold_stamps.json (scripts/pipe_stamps.py --fold --json)"}}
 
 
 def flop_per_sample(cfg) -> int:
@@ -169,6 +213,44 @@ def train_flop_per_step(cfg, batch: int, t_len: int, frames: int = 0) -> float:
     return 2.0 * 3.0 * batch * macs
 
 
+def train_bytes_per_step(cfg, batch: int, t_len: int, frames: int = 0) -> dict:
+    """HBM bytes one training step MUST move with this build's kernels ("design": every tensor a kernel reads or
+    writes counted once per kernel, fp32) and with nothing saved or staged at all ("floor": a layer reads its input and
+    writes its output, forward and backward, plus the skip sum).  Per layer and position, in floats (C = K = 64; DESIGN
+    section 5 has the derivation):
+      forward   x(t) 64 + x(t-d) 64 read; x' 64, tanh 64, sigmoid 64 written; skip sum 64 read + 64 written where t >= RF-1
+                [conditioned: + context 64 read]                                                     -> 448 [512]
+      backward  A' 64, P0 64 (the layer above's input gradient in scatter form), dskip 64 (t >= RF-1), tanh 64, sigmoid 64,
+                x(t) 64, x(t-d) 64 read; A' 64, P0 64 written                                          -> 576
+                [conditioned: + df|dg 128 written, and the context pass: df|dg 128 + context 64 + dctx 64 read, dctx 64 written]
+      floor     forward x 64 read, x' 64 written, skip 128; backward dx' 64, x 64 read, dx 64 written, dskip 64
+    Head per output position: 1344 forward (skip, a1 written and read, logits written, softmax + loss in place) + 2496
+    backward; embedding 64 forward, 256 backward (combine + gradient).  r3's two-half backward moved 896 per layer
+    position where this round's one-kernel form moves 576."""
+    C, Q = cfg["residual_channels"], cfg["input_channels"]
+    ds = dilations(cfg)
+    L, rf = len(ds), sum(ds) + cfg["stack_size"]
+    S = t_len - rf + 1
+    design = floor = 0
+    a = 0
+    for li, d in enumerate(ds):
+        a += d
+        n, ns = t_len - a, min(t_len - a, S)          # positions of the layer, positions that also feed the skip sum
+        last, first = li == L - 1, li == 0
+        fwd = n * (2 * C + (0 if last else C) + 2 * C + (C if frames else 0)) + ns * (C + (0 if first else C))
+        bwd = n * ((0 if last else 2 * C) + 4 * C + 2 * C) + ns * C
+        if frames:
+            bwd += n * (2 * C + 2 * C + C + 2 * C)
+        design += fwd + bwd
+        floor += n * (C + (0 if last else C)) + ns * 2 * C + n * ((0 if last else C) + C + C) + ns * C
+    head = S * (1344 + 2496) * (Q / 256.0)
+    embed = t_len * (C + 4 * C)
+    video = frames * 4096 + 3 * 3 * C * int(1.11 * t_len) if frames else 0
+    design += head + embed + video
+    floor += S * (C + Q) + S * (Q + C) + t_len * 2 * C
+    return {"design_bytes": 4.0 * batch * design, "floor_bytes": 4.0 * batch * floor}
+
+
 class clip_frames:
     """the reference fixes the clip length through module constants (160 frames <->
     160000 samples, wavenet.py:27-31).  BASELINE configs[2]/[3] use 32-frame clips: the
@@ -278,14 +360,39 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
             "param_sha256_per_rank": digests, "allreduce_path": sync.last_path,
             "allreduce_floats": sync.last_floats,
             "flop_per_step_per_gpu": flop_step, "flop_per_token": flop_step / (batch * (t_len - rf)),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
-                         "note": "fp32 model FLOP against the fp32 MFMA peak.  Since r3 the forward layers (audio-only: both products; "
-                                 "conditioned: the residual|skip product) and every weight-gradient product (wgrad2, the fused "
-                                 "backward's second half and conditioned pass) form each fp32 product on the bf16 matrix cores "
-                                 "(operands split exactly into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per 32x32x16 "
-                                 "block, fp32 accumulation: fp32-class error, DESIGN 4.3b / 4.4); the data-gradient products and "
-                                 "the head's convolutions run on v_mfma_f32_32x32x2_f32.  That is why a forward layer alone can exceed this peak's rate"}}
+            "roofline": train_roofline(flop_step, train_bytes_per_step(CFG, batch, t_len, frames), dt / steps,
+                                       "train_config3" if frames else "train_config2")}
+
+
+def train_roofline(flop_step: float, nbytes: dict, s_per_step: float, section: str) -> dict:
+    """What bounds a training step, three ways ("report both"): the HBM roof over the bytes the step must
+    move, the matrix cores priced against the unit the kernels actually issue, and the fp32-nominal figure of earlier
+    rounds.  The bytes a profiler counted come from this round's --pmc passes (profiles/), labelled as such."""
+    tf = flop_step / s_per_step / 1e12
+    gbps = nbytes["design_bytes"] / s_per_step / 1e9
+    bf3_peak = BF16_DENSE_PEAK_TFLOPS / 6.0
+    prof = profiled("step_totals", section)
+    out = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+           "algorithmic_bytes_per_step": nbytes["design_bytes"],
+           "floor_bytes_per_step": nbytes["floor_bytes"],
+           "floor_GBps": nbytes["floor_bytes"] / s_per_step / 1e9,
+           "traffic": None,
+           "traffic_profiled": ({"bytes_per_step": prof["bytes_per_step_fetch_x2_plus_write"],
+                                 "GBps_at_this_runs_step_time": prof["bytes_per_step_fetch_x2_plus_write"] / s_per_step / 1e9,
+                                 "frac_of_hbm_peak": prof["bytes_per_step_fetch_x2_plus_write"] / s_per_step / 1e9 / HBM_PEAK_GBPS,
+                                 "source": f"profiles/{PROFILE_TAG}_pmc_summary.json step_totals.{section} (separate --pmc passes of "
+                                           "scripts/train_steps.py: 2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of a step); "
+                                           "NOT measured by this run"} if prof else None),
+           "mfma": {"unit_used": "bf16 x 3: six v_mfma_f32_32x32x16_bf16 per fp32 32x32x16 block (every product of the layers, "
+                                 "the head and the weight gradients; the conditioned forward's x(t) / context blocks and the "
+                                 "video up-sampler still issue v_mfma_f32_32x32x2_f32)",
+                    "achieved": tf, "peak": bf3_peak, "unit": "TFLOP/s (fp32 model FLOP)", "frac": tf / bf3_peak,
+                    "fp32_nominal": {"peak": FP32_PEAK_TFLOPS, "frac": tf / FP32_PEAK_TFLOPS,
+                                     "note": "fp32 model FLOP over the fp32 MFMA peak: the figure of rounds 1-3, NOT a fraction of "
+                                             "a ceiling these kernels run against (an fp32-equivalent rate)"}},
+           "note": "the HBM roof binds on paper (bytes / 8 TB/s > FLOP x 6 / 2.5 PF); the layer kernels themselves are bound by "
+                   "vector-instruction issue -- the exact split of every operand into three bf16 planes (DESIGN 4.3c)"}
+    return out
 
 
 def trainer_fit_line(dev, steps=16):
@@ -691,20 +798,17 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_PEAK_TFLOPS,
                 # HBM-side bytes: not measurable from inside the run (hardware counters need a
-                # rocprofv3 --pmc pass) => null here; the last profiled figure is quoted beside it,
-                # labelled as such (FETCH_SIZE as reported + WRITE_SIZE of separate passes)
+                # rocprofv3 --pmc pass) => null here; this round's profiled figure is quoted beside it,
+                # labelled with the file it comes from (FETCH_SIZE as reported + WRITE_SIZE of separate passes)
                 "traffic": None,
-                "traffic_profiled": ({"bytes_per_launch": PMC_TRAFFIC[variant_used]["bytes_per_step_seq"] * BATCH * n_new,
-                                      "source": PMC_TRAFFIC[variant_used]["source"],
-                                      "note": "from earlier --pmc passes of this command, NOT this run; the 12.6 MB "
-                                              "of dilation queues stay in L2/MALL"}
-                                     if variant_used in PMC_TRAFFIC else None),
+                "traffic_profiled": headline_traffic(variant_used, n_new),
                 "algorithmic_bytes_per_launch": 2 * 30 * 64 * 4 * BATCH * n_new,  # 15,360 B per sample
                 "kernel": {1: "gen_generic_kernel", 2: "gen_stream64_kernel", 3: "gen_pipe_kernel<64>",
                            5: "gen_fold_kernel"}[variant_used],
                 "flop_per_launch": flops_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,
                 "note": "latency-bound: L-deep dependent chain per sample at batch 16 (DESIGN.md)",
+                **latency_floor(variant_used, elapsed / K / n_new * 1e6),
             },
         }
         if extras and isinstance(extras.get("batch_sweep"), dict) and "error" not in extras["batch_sweep"]:

@@ -72,6 +72,16 @@ if not WIDE:
       f" (min {hops[NS-1].min():.2f}, max {hops[NS-1].max():.2f})")
 print("sum compute %.2f us, sum hops %.2f us" % (compute.mean(0).mean(1).sum() + head.mean(),
                                                sum(h.mean() for h in hops)))
+if "--json" in sys.argv and not WIDE:
+    import json
+    path = sys.argv[sys.argv.index("--json") + 1]
+    json.dump({"variant": "fold" if FOLD else "pipe", "batch": B, "stages": NS - 1,
+               "note": "in-kernel s_memrealtime stamps of the diagnostic build (libmovenet_hip_stamps.so), averaged over steps 8..63 "
+                       "of one launch and the sequences: stage chain = inbox complete -> outbox sent, hop = outbox sent -> the next "
+                       "stage's inbox complete (the last hop: head -> stage 0), head = its inbox complete -> its send",
+               "step_us": float(step.mean()), "stage_chain_us": [float(compute[:, s].mean()) for s in range(NS - 1)],
+               "hop_us": [float(h.mean()) for h in hops], "head_us": float(head.mean()),
+               "shader_clock_MHz_median": float(np.median(mhz))}, open(path, "w"), indent=1)
 
 fine = np.zeros((16, 16, 64, 8), dtype=np.uint64)
 read_fine.argtypes = [C.c_void_p, C.c_size_t]

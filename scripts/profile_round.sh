@@ -7,7 +7,7 @@
 # pass that does not (r2: nine passes ended in SIGSEGV at process exit and were walked past;
 # profile_summary.py refuses a directory whose passes.txt is missing or holds a failure).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -46,4 +46,10 @@ for CFGN in 2 3; do
   pass ${P}_write /dev/null rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${P}_write -o p --output-format csv -- $TR
   pass ${P}_trace /dev/null rocprofv3 --kernel-trace --stats -d $OUT/${P}_trace -o t --output-format csv -- $TR
 done
+# 4. the generator's step against its dependent chain: in-kernel stamps of the diagnostic build
+if [ -f $R/movenet_amd/lib/libmovenet_hip_stamps.so ]; then
+  export MOVENET_HIP_LIB=$R/movenet_amd/lib/libmovenet_hip_stamps.so
+  pass fold_stamps $OUT/fold_stamps.txt python3 $R/scripts/pipe_stamps.py --fold --json $OUT/fold_stamps.json
+  unset MOVENET_HIP_LIB
+fi
 echo "all passes ok" | tee -a $OUT/passes.txt

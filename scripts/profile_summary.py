@@ -21,7 +21,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 # every pass of scripts/profile_round.sh must have exited 0 (r2: passes that ended in SIGSEGV at
@@ -98,6 +98,41 @@ for section, pre in (("kernels", "tr2"), ("kernels_config3", "tr3")):
             e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = f["FETCH_SIZE"], w["WRITE_SIZE"]
             e["hbm_GBps_fetch_x2_corrected"] = round((2 * f["FETCH_SIZE"] * 1024 / df + w["WRITE_SIZE"] * 1024 / dw), 1)
         summary[section][k] = e
+
+
+def step_total(pre):
+    """HBM bytes of ONE training step, summed over EVERY kernel of the fetch / write passes (2 x FETCH_SIZE: the guide's
+    gfx950 correction for 16-byte streams; WRITE_SIZE as reported), steps = launches of the loss kernel."""
+    tot = {}
+    for kind in ("fetch", "write"):
+        cf = one(f"{pre}_{kind}/**/*counter_collection.csv")
+        if not cf:
+            return None
+        s, steps = 0.0, set()
+        for r in csv.DictReader(open(cf)):
+            if r["Counter_Name"] == ("FETCH_SIZE" if kind == "fetch" else "WRITE_SIZE"):
+                s += float(r["Counter_Value"])
+            if "softmax_ce_fwd" in r["Kernel_Name"]:
+                steps.add(r["Dispatch_Id"])
+        tot[kind] = (s * 1024.0, max(len(steps), 1))
+    f, w = tot["fetch"][0] / tot["fetch"][1], tot["write"][0] / tot["write"][1]
+    return {"steps_profiled": tot["fetch"][1], "FETCH_SIZE_bytes_per_step_as_reported": f, "WRITE_SIZE_bytes_per_step": w,
+            "bytes_per_step_fetch_x2_plus_write": 2 * f + w}
+
+
+summary["step_totals"] = {"train_config2": step_total("tr2"), "train_config3": step_total("tr3")}
+# the generator's step against its dependent chain (scripts/pipe_stamps.py --fold --json): scaled to the product's step
+fs = one("fold_stamps.json")
+if fs:
+    st = json.load(open(fs))
+    b = one("bench.json")
+    if b:
+        try:
+            st["product_step_us"] = json.load(open(b))["us_per_sample_step"]
+            st["product_over_stamped"] = st["product_step_us"] / st["step_us"]
+        except (ValueError, KeyError):
+            pass
+    json.dump(st, open(os.path.join(dst, f"{tag}_fold_stamps.json"), "w"), indent=1)
 gf, gw = counters("gen_fetch"), counters("gen_write")
 for k in gf:
     if "gen_" in k and "kernel" in k and k in gw:
