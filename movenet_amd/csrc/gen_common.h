@@ -57,6 +57,9 @@ __device__ __forceinline__ float rs_elem(const float *rw, const float *sw, int C
 }
 
 
+// class counts the 256-wide heads of the tuned generators take (padded at pack time: generate_fold.hip)
+inline bool head_q_ok(int q) { return q == 64 || q == 128 || q == 256; }
+
 // ---- PIPE variant (generate_pipe.hip) ------------------------------------
 bool pipe_ok(const mvn_dims *d);
 int pipe_stages(const mvn_dims *d);

@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
     if (tid == 0 && t + 1 < a.n_given) next_given = samples[t + 1];
     if (tid < 64) {
       int idx_t = ired[5], idx_p = ired[4];
-      idx_t = min(max(idx_t, 0), Q - 1);
-      idx_p = min(idx_p, Q - 1);
+      idx_t = min(max(idx_t, 0), a.Q - 1);
+      idx_p = min(idx_p, a.Q - 1);
       float v = E1[idx_t * C + tid];
       if (idx_p >= 0) v += E0[idx_p * C + tid];
       xcat[64 + tid] = v;
@@ -454,8 +454,10 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
     lg += b2[tid];
 
     if (do_head) {
-      if (a.logits_out && u >= a.logits_t0)
-        a.logits_out[((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q + tid] = lg;
+      // (r4: a.Q in {64, 128, 256}; classes >= a.Q are the padding of the 256-wide head: logit -inf by their packed
+      // bias, no probability in either softmax, never written out)
+      if (a.logits_out && u >= a.logits_t0 && tid < a.Q)
+        a.logits_out[((size_t)b * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * a.Q + tid] = lg;
       // softmax -> [/T] -> softmax, one class per thread
       float m = wave_max(lg);
       if (lane == 0) red[0 + wave] = m;
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
       if (lane == 0) red[8 + wave] = m2;
       lds_barrier();
       m2 = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
-      const float e2 = expf(p - m2);
+      const float e2 = tid < a.Q ? expf(p - m2) : 0.f;
       float s2 = wave_sum(e2);
       if (lane == 0) red[12 + wave] = s2;
       lds_barrier();
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
         if (wave > 2) base += red[18];
         const float total = ((red[16] + red[17]) + red[18]) + red[19];
         const float target = philox_uniform(a.seed, (uint32_t)u, (uint32_t)b) * total;
-        cand = (base + c > target) ? tid : Q - 1;
+        cand = (base + c > target) ? tid : a.Q - 1;
         // first class whose cdf exceeds the target
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
@@ -614,23 +616,34 @@ __global__ void pack_layer_s64_kernel(const float *fw, const float *gw, const fl
   }
 }
 
+// `qm`: the model's class count (64, 128 or 256); the head runs 256 wide, classes >= qm are padding (zero rows and
+// columns, conv2 bias -inf)
 __global__ void pack_head_s64_kernel(const float *w1, const float *b1, const float *w2,
-                                     const float *b2, float *__restrict__ dst) {
+                                     const float *b2, float *__restrict__ dst, int qm) {
   using namespace s64;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n1 = W1_F4 * 4, n2 = W2_F4 * 4;
   if (i < n1) {
     const int j = i & 3, v = i >> 2, q = v & 255, k4 = v >> 8;
-    dst[i] = w1[(size_t)q * 64 + k4 * 4 + j];
+    dst[i] = q < qm ? w1[(size_t)q * 64 + k4 * 4 + j] : 0.f;
   } else if (i < n1 + 256) {
-    dst[i] = b1[i - n1];
+    dst[i] = i - n1 < qm ? b1[i - n1] : 0.f;
   } else if (i < n1 + 256 + n2) {
     const int ii = i - n1 - 256;
-    const int j = ii & 3, v = ii >> 2, q = v & 255, k4 = v >> 8;
-    dst[i] = w2[(size_t)q * 256 + k4 * 4 + j];
+    const int j = ii & 3, v = ii >> 2, q = v & 255, k4 = v >> 8, k = k4 * 4 + j;
+    dst[i] = (q < qm && k < qm) ? w2[(size_t)q * qm + k] : 0.f;
   } else if (i < n1 + 256 + n2 + 256) {
-    dst[i] = b2[i - n1 - 256 - n2];
+    const int q = i - n1 - 256 - n2;
+    dst[i] = q < qm ? b2[q] : -INFINITY;
   }
+}
+// the embedding tables of a model with qm classes in the STREAM layout's 256 rows (rows >= qm: zero, never gathered)
+__global__ void pack_embed_s64_kernel(const float *__restrict__ causal_w, float *__restrict__ dst, int qm) {
+  using namespace s64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= EMB_FLOATS) return;
+  const int tap = i / (Q * C), r = i - tap * Q * C, q = r / C, c = r - q * C;
+  dst[i] = q < qm ? causal_w[((size_t)c * qm + q) * 2 + tap] : 0.f;
 }
 
 // wide models keep more weight loads in flight with a 1024-thread workgroup
@@ -690,7 +703,7 @@ __global__ void pack_ctx_generic_kernel(const float *wcf, const float *bcf, cons
 }
 
 static bool stream_ok(const mvn_dims *d) {
-  return d->residual_channels == 64 && d->skip_channels == 64 && d->input_channels == 256 &&
+  return d->residual_channels == 64 && d->skip_channels == 64 && head_q_ok(d->input_channels) &&
          n_layers(d) <= 80;
 }
 
@@ -765,7 +778,7 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   }
   if (requested == MVN_GEN_PIPE) {
     if (!pipe_fits) {
-      mvn::set_error("PIPE variant needs C=K in {64,128}, Q=256, 256 CUs and batch <= %d for these "
+      mvn::set_error("PIPE variant needs C=K in {64,128}, Q in {64,128,256}, 256 CUs and batch <= %d for these "
                      "dims (stages per sequence: ceil(L/4)+1 at C=64, L+1 at C=128; 32 per XCD)",
                      mvn::pipe_ok(dims) ? mvn::pipe_max_batch(dims) : 0);
       return MVN_ERR_UNSUPPORTED;
@@ -774,7 +787,7 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   }
   if (requested == MVN_GEN_FOLD) {
     if (!fold_fits) {
-      mvn::set_error("FOLD variant needs C=K=64, Q=256, 256 CUs and batch <= %d for these dims "
+      mvn::set_error("FOLD variant needs C=K=64, Q in {64,128,256}, 256 CUs and batch <= %d for these dims "
                      "(ceil(L/3)+1 stages per sequence, 32 per XCD)",
                      mvn::fold_ok(dims) ? mvn::fold_max_batch(dims) : 0);
       return MVN_ERR_UNSUPPORTED;
@@ -792,7 +805,7 @@ int mvn_gen_variant(const mvn_dims *dims, int requested, int batch) {
   }
   if (requested == MVN_GEN_STREAM) {
     if (!mvn::stream_ok(dims)) {
-      mvn::set_error("STREAM variant needs C=K=64, Q=256, <=80 layers");
+      mvn::set_error("STREAM variant needs C=K=64, Q in {64,128,256}, <=80 layers");
       return MVN_ERR_UNSUPPORTED;
     }
     return MVN_GEN_STREAM;
@@ -868,12 +881,15 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
   }
   const int C = dims->residual_channels, K = dims->skip_channels, Q = dims->input_channels;
   const int L = mvn::n_layers(dims);
-  {
+  if (variant == MVN_GEN_STREAM) {  // (its layout is 256 classes wide whatever the model's Q: padded)
+    hipLaunchKernelGGL(mvn::pack_embed_s64_kernel, dim3((mvn::s64::EMB_FLOATS + 255) / 256), dim3(256), 0, stream,
+                       p->causal_w, packed, Q);
+  } else {
     const int n = 2 * Q * C;
     hipLaunchKernelGGL(mvn::pack_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
                        p->causal_w, packed, Q, C);
   }
-  float *lw = packed + 2 * (size_t)Q * C;
+  float *lw = packed + (variant == MVN_GEN_STREAM ? (size_t)mvn::s64::EMB_FLOATS : 2 * (size_t)Q * C);
   if (variant == MVN_GEN_STREAM) {
     const int n = mvn::s64::LAYER_F4 * 4;
     for (int l = 0; l < L; ++l)
@@ -882,7 +898,7 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
                          p->skip_w[l], p->skip_b[l], lw + (size_t)l * n);
     const int nh = mvn::s64::HEAD_F4 * 4;
     hipLaunchKernelGGL(mvn::pack_head_s64_kernel, dim3((nh + 255) / 256), dim3(256), 0, stream,
-                       p->head1_w, p->head1_b, p->head2_w, p->head2_b, lw + (size_t)L * n);
+                       p->head1_w, p->head1_b, p->head2_w, p->head2_b, lw + (size_t)L * n, Q);
   } else {
     const size_t n = 4 * (size_t)C * C + (size_t)C * (C + K) + (C + K);
     for (int l = 0; l < L; ++l)

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
 
     int idx_cur = 0, idx_prev = -1;
     auto send_h0 = [&](unsigned ep) {  // wave 0: xp = the causal conv's two embedding rows, zl = sk = 0
-      const int ic = min(max(idx_cur, 0), Q - 1), ip = min(idx_prev, Q - 1);
+      const int ic = min(max(idx_cur, 0), a.Q - 1), ip = min(idx_prev, a.Q - 1);
       float v = E1[ic * C + lane];
       if (ip >= 0) v += E0[ip * C + lane];
       put_granule(outbox + lane, ep, v, fast_edge);
@@ -700,9 +700,9 @@ __global__ __launch_bounds__(512, 2) void gen_fold_kernel(GenArgs a, u64 *hand, 
         if (do_head) {
           const f4 lv = ((const f4 *)lgb)[lane];
           const float lg[4] = {lv.x, lv.y, lv.z, lv.w};
-          if (a.logits_out && u >= a.logits_t0)
-            ((f4 *)(a.logits_out + ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
-          const int pick = choose_class(lg, a.temperature, uni, lane, Q);
+          if (a.logits_out && u >= a.logits_t0 && 4 * lane < a.Q)  // (rows of a.Q logits: the padding is not written)
+            ((f4 *)(a.logits_out + ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * a.Q))[lane] = lv;
+          const int pick = choose_class(lg, a.temperature, uni, lane, a.Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
           idx_cur = next_idx;
@@ -803,22 +803,28 @@ __global__ void pack_fold_stage_kernel(FoldLayers p, float *__restrict__ dst) {
   dst[i] = (float)v;
 }
 
+// `qm`: the MODEL's class count (64, 128 or 256).  The head always runs 256 classes wide: classes >= qm are padding --
+// zero rows and columns, conv2 bias -inf, so that their logits are -inf (probability 0 in the first softmax;
+// choose_class masks them in the second) and they are never picked.
 __global__ void pack_fold_head_kernel(const float *w1, const float *b1, const float *w2, const float *b2,
-                                      const float *sw_last, const float *sb_last, float *__restrict__ dst) {
+                                      const float *sw_last, const float *sb_last, float *__restrict__ dst, int qm) {
   using namespace fold;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < W1_F) {
     // conv1: [8][tid (512)] float4, thread (o1 = tid >> 1, q1 = tid & 1) owns 32 inputs
     const int e = i & 3, v = i >> 2, tid = v & (NT - 1), i4 = v >> 9;
-    dst[i] = w1[(size_t)(tid >> 1) * C + 32 * (tid & 1) + 4 * i4 + e];
+    const int o = tid >> 1;
+    dst[i] = o < qm ? w1[(size_t)o * C + 32 * (tid & 1) + 4 * i4 + e] : 0.f;
   } else if (i < W1_F + Q) {
-    dst[i] = b1[i - W1_F];
+    dst[i] = i - W1_F < qm ? b1[i - W1_F] : 0.f;
   } else if (i < W1_F + Q + W2_F) {
     const int ii = i - W1_F - Q;
     const int e = ii & 3, v = ii >> 2, tid = v & (NT - 1), rest = v >> 9, r = rest >> 3, i8 = rest & 7;
-    dst[i] = w2[(size_t)(4 * (tid >> 3) + r) * Q + 32 * (tid & 7) + 4 * i8 + e];
+    const int o = 4 * (tid >> 3) + r, k = 32 * (tid & 7) + 4 * i8 + e;
+    dst[i] = (o < qm && k < qm) ? w2[(size_t)o * qm + k] : 0.f;
   } else if (i < W1_F + Q + W2_F + Q) {
-    dst[i] = b2[i - W1_F - Q - W2_F];
+    const int o = i - W1_F - Q - W2_F;
+    dst[i] = o < qm ? b2[o] : -INFINITY;
   } else if (i < W1_F + Q + W2_F + Q + WSL_F) {
     // last layer's skip 1x1: [2][tid (512)] float4, thread (cs = tid >> 3, q8 = tid & 7) owns 8 inputs
     const int ii = i - (W1_F + Q + W2_F + Q);
@@ -829,16 +835,17 @@ __global__ void pack_fold_head_kernel(const float *w1, const float *b1, const fl
   }
 }
 
-__global__ void pack_fold_embed_kernel(const float *__restrict__ causal_w, float *__restrict__ dst) {
+__global__ void pack_fold_embed_kernel(const float *__restrict__ causal_w, float *__restrict__ dst, int qm) {
   using namespace fold;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= EMB_F) return;
   const int tap = i / (Q * C), r = i - tap * Q * C, qq = r / C, c = r - qq * C;
-  dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
+  dst[i] = qq < qm ? causal_w[((size_t)c * qm + qq) * 2 + tap] : 0.f;
 }
 
 bool fold_ok(const mvn_dims *d) {
-  return d->residual_channels == 64 && d->skip_channels == 64 && d->input_channels == 256 &&
+  // (r4: Q in {64, 128, 256} -- the head runs 256 classes wide, a smaller model's are padded at pack time)
+  return d->residual_channels == 64 && d->skip_channels == 64 && head_q_ok(d->input_channels) &&
          n_layers(d) >= 1 && (n_layers(d) + fold::LPS - 1) / fold::LPS + 1 <= PIPE_XCD_CUS;
 }
 int fold_stages(const mvn_dims *d) { return (n_layers(d) + fold::LPS - 1) / fold::LPS + 1; }
@@ -868,7 +875,7 @@ size_t fold_hand_floats(const mvn_dims *d, int batch) {
 int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {
   using namespace fold;
   const int L = n_layers(d), NSL = fold_stages(d) - 1;
-  hipLaunchKernelGGL(pack_fold_embed_kernel, dim3((EMB_F + 255) / 256), dim3(256), 0, s, p->causal_w, packed);
+  hipLaunchKernelGGL(pack_fold_embed_kernel, dim3((EMB_F + 255) / 256), dim3(256), 0, s, p->causal_w, packed, d->input_channels);
   for (int st = 0; st < NSL; ++st) {
     FoldLayers fl;
     for (int j = 0; j < 4; ++j) {
@@ -891,7 +898,7 @@ int fold_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t
   const bool tail_real = l_tail < L;
   hipLaunchKernelGGL(pack_fold_head_kernel, dim3((HEAD_F + 255) / 256), dim3(256), 0, s, p->head1_w, p->head1_b,
                      p->head2_w, p->head2_b, tail_real ? p->skip_w[l_tail] : nullptr,
-                     tail_real ? p->skip_b[l_tail] : nullptr, packed + EMB_F + (size_t)NSL * STAGE_F);
+                     tail_real ? p->skip_b[l_tail] : nullptr, packed + EMB_F + (size_t)NSL * STAGE_F, d->input_channels);
   return check_hip(hipGetLastError(), "fold_pack");
 }
 

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
     // and the next step's first hop.
     int idx_cur = 0, idx_prev = -1;
     auto send_h0 = [&](unsigned ep) {  // wave 0: granules c = residual, C + c = skip sum 0
-      const int ic = min(max(idx_cur, 0), Q - 1), ip = min(idx_prev, Q - 1);
+      const int ic = min(max(idx_cur, 0), a.Q - 1), ip = min(idx_prev, a.Q - 1);
 #pragma unroll
       for (int j = 0; j < C / 64; ++j) {
         const int ch = lane + 64 * j;
@@ -559,10 +559,10 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
           // lane i owns classes 4i..4i+3; every reduction is intra-wave (DPP + readlane)
           const f4 lv = ((const f4 *)lgb)[lane];
           float lg[4] = {lv.x, lv.y, lv.z, lv.w};
-          if (a.logits_out && u >= a.logits_t0)
+          if (a.logits_out && u >= a.logits_t0 && 4 * lane < a.Q)  // (rows of a.Q logits: the padding is not written)
             ((f4 *)(a.logits_out +
-                    ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * Q))[lane] = lv;
-          const int pick = choose_class(lg, a.temperature, uni, lane, Q);
+                    ((size_t)bq * (a.n_total - a.logits_t0) + (u - a.logits_t0)) * a.Q))[lane] = lv;
+          const int pick = choose_class(lg, a.temperature, uni, lane, a.Q);
           if (u >= a.n_given) next_idx = pick;
           idx_prev = idx_cur;
           idx_cur = next_idx;
@@ -616,35 +616,40 @@ __global__ void pack_layer_pipe_kernel(const float *fw, const float *gw, const f
     dst[i] = rs_elem(rw, sw, C, row, k);
 }
 
+// `qm`: the model's class count (64, 128 or 256); the head runs 256 wide, classes >= qm are padding (zero rows and
+// columns, conv2 bias -inf: see pack_fold_head_kernel)
 template <int CC>
 __global__ void pack_head_pipe_kernel(const float *w1, const float *b1, const float *w2,
-                                      const float *b2, float *__restrict__ dst) {
+                                      const float *b2, float *__restrict__ dst, int qm) {
   using P = PipeCfg<CC>;
   constexpr int C = P::C, Q = P::Q, NT = P::NT, W1N = P::W1N;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < P::W1_F) {
     // conv1: [W1N/4][tid (512)] float4, thread (o1 = tid>>1, q1 = tid&1) owns W1N inputs
     const int e = i & 3, v = i >> 2, tid = v & (NT - 1), i4 = v >> 9;
-    dst[i] = w1[(size_t)(tid >> 1) * C + W1N * (tid & 1) + 4 * i4 + e];
+    const int o = tid >> 1;
+    dst[i] = o < qm ? w1[(size_t)o * C + W1N * (tid & 1) + 4 * i4 + e] : 0.f;
   } else if (i < P::W1_F + Q) {
-    dst[i] = b1[i - P::W1_F];
+    dst[i] = i - P::W1_F < qm ? b1[i - P::W1_F] : 0.f;
   } else if (i < P::W1_F + Q + P::W2_F) {
     const int ii = i - P::W1_F - Q;
     const int e = ii & 3, v = ii >> 2, tid = v & (NT - 1), rest = v >> 9, r = rest >> 3, i8 = rest & 7;
-    dst[i] = w2[(size_t)(4 * (tid >> 3) + r) * Q + 32 * (tid & 7) + 4 * i8 + e];
+    const int o = 4 * (tid >> 3) + r, k = 32 * (tid & 7) + 4 * i8 + e;
+    dst[i] = (o < qm && k < qm) ? w2[(size_t)o * qm + k] : 0.f;
   } else if (i < P::HEAD_F) {
-    dst[i] = b2[i - P::W1_F - Q - P::W2_F];
+    const int o = i - P::W1_F - Q - P::W2_F;
+    dst[i] = o < qm ? b2[o] : -INFINITY;
   }
 }
 
 template <int CC>
-__global__ void pack_embed_pipe_kernel(const float *__restrict__ causal_w, float *__restrict__ dst) {
+__global__ void pack_embed_pipe_kernel(const float *__restrict__ causal_w, float *__restrict__ dst, int qm) {
   using P = PipeCfg<CC>;
   constexpr int C = P::C, Q = P::Q;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P::EMB_F) return;
   const int tap = i / (Q * C), r = i - tap * Q * C, qq = r / C, c = r - qq * C;
-  dst[i] = causal_w[((size_t)c * Q + qq) * 2 + tap];
+  dst[i] = qq < qm ? causal_w[((size_t)c * qm + qq) * 2 + tap] : 0.f;
 }
 
 template <int CC>
@@ -667,7 +672,7 @@ __global__ void pack_ctx_pipe_kernel(const float *wcf, const float *bcf, const f
 
 bool pipe_ok(const mvn_dims *d) {
   const int c = d->residual_channels;
-  return (c == 64 || c == 128) && d->skip_channels == c && d->input_channels == 256 &&
+  return (c == 64 || c == 128) && d->skip_channels == c && head_q_ok(d->input_channels) &&
          n_layers(d) >= 1;
 }
 static int pipe_lps(const mvn_dims *d) { return d->residual_channels == 64 ? 4 : 1; }
@@ -698,14 +703,14 @@ static int pipe_pack_t(const mvn_dims *d, const mvn_params *p, float *packed, hi
   using P = PipeCfg<CC>;
   const int L = n_layers(d);
   hipLaunchKernelGGL(pack_embed_pipe_kernel<CC>, dim3((P::EMB_F + 255) / 256), dim3(256), 0, s,
-                     p->causal_w, packed);
+                     p->causal_w, packed, d->input_channels);
   for (int l = 0; l < L; ++l)
     hipLaunchKernelGGL(pack_layer_pipe_kernel<CC>, dim3((P::LAYER_F + 255) / 256), dim3(256), 0, s,
                        p->filter_w[l], p->gate_w[l], p->residual_w[l], p->residual_b[l], p->skip_w[l],
                        p->skip_b[l], packed + P::EMB_F + (size_t)l * P::LAYER_F);
   hipLaunchKernelGGL(pack_head_pipe_kernel<CC>, dim3((P::HEAD_F + 255) / 256), dim3(256), 0, s,
                      p->head1_w, p->head1_b, p->head2_w, p->head2_b,
-                     packed + P::EMB_F + (size_t)L * P::LAYER_F);
+                     packed + P::EMB_F + (size_t)L * P::LAYER_F, d->input_channels);
   return check_hip(hipGetLastError(), "pipe_pack");
 }
 int pipe_pack(const mvn_dims *d, const mvn_params *p, float *packed, hipStream_t s) {

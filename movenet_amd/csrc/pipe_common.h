@@ -501,8 +501,10 @@ __device__ __forceinline__ int choose_class(const float (&lg)[4], float temperat
   // max over p = rs exactly: the largest e is exp(0) = 1.0 (v_exp_f32 of 0 is exact), 1.0 * rs = rs,
   // and rounding is monotone for the others (e <= 1)  -- one wave-wide max reduction less per step
   const float m2 = rs;
+  // (classes >= Q are the padding of a head that runs 256 wide for a smaller model: logit -inf, p = 0 -- and no mass
+  // in this second softmax either, where exp(0 - m2) would give each of them some)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) e[k] = __expf(p[k] - m2);
+  for (int k = 0; k < 4; ++k) e[k] = 4 * lane + k < Q ? __expf(p[k] - m2) : 0.f;
   const float s2sum = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
   const float rs2 = __builtin_amdgcn_rcpf(s2sum);
 #pragma unroll

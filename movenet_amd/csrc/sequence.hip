@@ -1026,6 +1026,33 @@ static int side_stream(SideStream **out) {
 
 using namespace mvn;
 
+// The head's four convolution-shaped products as bf16 x 3 strip kernels (fused_fwd_bf3.h) for Q in {64, 128, 256}
+// (r4: the reference's own experiments run Q = 128, experiments/03_kinetics_scale_up.mk:7-10): conv1 = K 64 -> Q rows
+// in one workgroup, conv2 = Q -> Q in row blocks of 64, their data gradients with the weights transposed.
+template <int QQ>
+static int head_fwd1_bf3(const DenseStripArgs &da, const mvn_params *p, int Kc, float *img, int batch, hipStream_t s) {
+  launch_ds3_pack<64, QQ>(p->head1_w, Kc, p->head1_b, QQ, img, s);
+  launch_ds3_pack<QQ, 64>(p->head2_w, QQ, p->head2_b, QQ, img + DS3_IMG1_F, s);
+  return launch_dense_strip_bf3<64, QQ, IN_LRELU, OUT_BIAS_LRELU>(da, img, QQ, batch, s);
+}
+template <int QQ>
+static int head_fwd2_bf3(const DenseStripArgs &da, float *img, int batch, hipStream_t s) {
+  return launch_dense_strip_bf3<QQ, 64, IN_ID, OUT_BIAS>(da, img + DS3_IMG1_F, QQ, batch, s);
+}
+template <int QQ>
+static int head_bwd2_bf3(const DenseStripArgs &da, const mvn_params *p, float *img, int batch, hipStream_t s) {
+  launch_ds3_pack<QQ, 64, true>(p->head2_w, QQ, nullptr, QQ, img, s);
+  return launch_dense_strip_bf3<QQ, 64, IN_ID, OUT_MUL_DLRELU, true>(da, img, QQ, batch, s);
+}
+template <int QQ>
+static int head_bwd1_bf3(const DenseStripArgs &da, const mvn_params *p, int Kc, float *img, int batch, hipStream_t s) {
+  launch_ds3_pack<QQ, 64, true>(p->head1_w, Kc, nullptr, Kc, img + 4 * DS3_IMG2_F, s);
+  return launch_dense_strip_bf3<QQ, 64, IN_ID, OUT_MUL_DLRELU, true>(da, img + 4 * DS3_IMG2_F, Kc, batch, s);
+}
+#define MVN_HEAD_Q(call_)                               \
+  (Q == 256 ? call_<256> : Q == 128 ? call_<128> : call_<64>)
+static bool head_q_strip(int Q) { return Q == 256 || Q == 128 || Q == 64; }
+
 extern "C" {
 
 int mvn_padded_len(int n) { return n <= 0 ? 0 : (n + 63) / 64 * 64; }
@@ -1192,21 +1219,21 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     h1.ldw = Kc; h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v;
     h1.t_out_end = g.pad + g.S; h1.aligned_out = 1;
     // Q = 256, K = 64: the strip form reads the skip sum once (fused_fwd.h); MOVENET_HIP_NO_DENSE_STRIP=1: A/B
-    const bool strip = Q == 256 && Kc == 64 && !f16 && [] {
+    const bool strip_ok = Kc == 64 && !f16 && [] {
       const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
       return !(e && e[0] == '1');
     }();
+    const bool strip = strip_ok && Q == 256;  // (the fp32 strips: Q = 256 only)
     // r3: both head convolutions as strip kernels on the bf16 matrix cores (fused_fwd_bf3.h), their LDS images
     // packed once per call behind the layers' in the z scratch
     const size_t img_off = (size_t)g.L * std::max(FS3_PACK_F, FSC_PACK_F);
-    if (strip && forward_bf3_enabled() && head_bf3_enabled() && (size_t)g.act >= img_off + DS3_IMG_F) head_img = buf->z + img_off;
+    if (strip_ok && head_q_strip(Q) && forward_bf3_enabled() && head_bf3_enabled() && (size_t)g.act >= img_off + DS3_IMG_F)
+      head_img = buf->z + img_off;
     if (head_img) {
       DenseStripArgs da;
       da.t_begin = h1.t_begin; da.t_end = h1.t_end; da.t_out_end = h1.t_out_end;
       da.wmat = p->head1_w; da.ldw = Kc; da.bias = p->head1_b; da.xin = skipv; da.yout = a1v; da.ref = a1v;
-      launch_ds3_pack<64, 256>(p->head1_w, Kc, p->head1_b, Q, head_img, s);
-      launch_ds3_pack<256, 64>(p->head2_w, Q, p->head2_b, Q, head_img + DS3_IMG1_F, s);
-      const int rc2 = launch_dense_strip_bf3<64, 256, IN_LRELU, OUT_BIAS_LRELU>(da, head_img, Q, batch, s);
+      const int rc2 = MVN_HEAD_Q(head_fwd1_bf3)(da, p, Kc, head_img, batch, s);
       if (rc2) return rc2;
     } else if (strip) {
       DenseStripArgs da;
@@ -1234,7 +1261,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       DenseStripArgs da;
       da.t_begin = h2.t_begin; da.t_end = h2.t_end; da.t_out_end = h2.t_out_end;
       da.wmat = p->head2_w; da.ldw = Q; da.bias = p->head2_b; da.xin = a1v; da.yout = h2.yout; da.ref = a1v;
-      const int rc2 = launch_dense_strip_bf3<256, 64, IN_ID, OUT_BIAS>(da, head_img + DS3_IMG1_F, Q, batch, s);
+      const int rc2 = MVN_HEAD_Q(head_fwd2_bf3)(da, head_img, batch, s);
       if (rc2) return rc2;
     } else if (strip2) {
       // two row blocks of 128: a1 is read twice instead of once per 64-row block (four times)
@@ -1353,7 +1380,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   float *bwd_head_img = nullptr;
   {
     const size_t off = (size_t)g.L * std::max(FS3_PACK_F, FSC_PACK_F) + DS3_IMG_F;
-    if (Q == 256 && fwd->z && forward_bf3_enabled() && head_bf3_enabled() && (size_t)g.act >= off + DS3_BWD_IMG_F)
+    if (head_q_strip(Q) && Kc == 64 && fwd->z && forward_bf3_enabled() && head_bf3_enabled() && (size_t)g.act >= off + DS3_BWD_IMG_F)
       bwd_head_img = fwd->z + off;
   }
   if (!dout) {
@@ -1386,8 +1413,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       DenseStripArgs da;
       da.t_begin = d2.t_begin; da.t_end = d2.t_end; da.t_out_end = d2.t_out_end;
       da.wmat = p->head2_w; da.ldw = Q; da.bias = nullptr; da.xin = dlog; da.yout = da1; da.ref = a1v;
-      launch_ds3_pack<256, 64, true>(p->head2_w, Q, nullptr, Q, bwd_head_img, s);
-      rc = launch_dense_strip_bf3<256, 64, IN_ID, OUT_MUL_DLRELU, true>(da, bwd_head_img, Q, batch, s);
+      rc = MVN_HEAD_Q(head_bwd2_bf3)(da, p, bwd_head_img, batch, s);
       if (rc) return rc;
     } else {
       launch_gemm_staged(d2, Q, batch, s);
@@ -1411,8 +1437,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       DenseStripArgs da;
       da.t_begin = d1.t_begin; da.t_end = d1.t_end; da.t_out_end = d1.t_out_end;
       da.wmat = p->head1_w; da.ldw = Kc; da.bias = nullptr; da.xin = da1; da.yout = dskip; da.ref = skipv;
-      launch_ds3_pack<256, 64, true>(p->head1_w, Kc, nullptr, Kc, bwd_head_img + 4 * DS3_IMG2_F, s);
-      rc = launch_dense_strip_bf3<256, 64, IN_ID, OUT_MUL_DLRELU, true>(da, bwd_head_img + 4 * DS3_IMG2_F, Kc, batch, s);
+      rc = MVN_HEAD_Q(head_bwd1_bf3)(da, p, Kc, bwd_head_img, batch, s);
       if (rc) return rc;
     } else {
       launch_gemm_staged(d1, Kc, batch, s);
