@@ -78,4 +78,14 @@ out["config3 (config 2 + video, F=32 -> T=32000, B=8)"] = dict(
     generate_greedy=generate_rate(m, 8, 16000, video=video), train=train_rate(m, 8, 32000, video=video))
 m = model_of(c5)
 out["config5 (L=60, C=128, 22.05 kHz, fp32)"] = dict(generate_b1=generate_rate(m, 1, 22050), generate_b4=generate_rate(m, 4, 22050))
+# the reference's OWN experiment shapes (Q = 128: experiments/03_kinetics_scale_up.mk:7-10, :64-67,
+# 04_kinetics_receptive_field.mk:8-11); r4: Q in {64, 128} takes the pipelined generators and the head's strip kernels
+W.MAX_VIDEO_FRAMES, W.MAX_AUDIO_FRAMES = 160, 160000
+for name, cfg, B, n_new, T in (
+        ("reference shape (L=30, Q=128, C=64, B=16)", dict(layer_size=10, stack_size=3, input_channels=128, residual_channels=64, skip_channels=64), 16, 16000, 16000),
+        ("reference shape (L=14, Q=128, C=16, layer_size=14: RF 16384, B=4)", dict(layer_size=14, stack_size=1, input_channels=128, residual_channels=16, skip_channels=16), 4, 2000, 32000),
+        ("reference shape (L=4, Q=128, C=32, B=8)", dict(layer_size=2, stack_size=2, input_channels=128, residual_channels=32, skip_channels=32), 8, 8000, 16000)):
+    m = model_of(cfg)
+    variant = N.lib().mvn_gen_variant(m._dims, N.GEN_AUTO, B)
+    out[name] = dict(generate_greedy=dict(generate_rate(m, B, n_new), kernel_variant=int(variant)), train=train_rate(m, B, T))
 print(json.dumps(out, indent=1))
