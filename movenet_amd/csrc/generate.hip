@@ -298,6 +298,8 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
   float *red = a1 + 256;            // [8][4]
   int *ired = (int *)(red + 32);    // [8]: [0..3] per-wave candidate, [4] prev idx, [5] cur idx
   float *pastAll = red + 32 + 8;    // [L][64]
+  float *pctx = pastAll + (size_t)L * 64;  // [L][128] context-conv terms of the step (conditioned runs only)
+  float *cvec = pctx + (a.ctx_tm ? (size_t)L * 128 : 0);  // [64] the step's context column
 
   const f4 *wl = (const f4 *)(a.w + EMB_FLOATS);
   const f4 *head = wl + (size_t)L * LAYER_F4;
@@ -341,7 +343,26 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
       xcat[64 + tid] = v;
     }
     skipacc = 0.f;
+    if (a.ctx_tm && tid < 64) cvec[tid] = a.ctx_tm[(size_t)b * a.ctx_stride_b + (size_t)t * C + tid];
     __syncthreads();  // pastAll landed (vmcnt drained here once per step)
+    if (a.ctx_tm) {
+      // r4: local conditioning (build definition): f | g += Wc ctx(t) + bc for every layer.  None of it
+      // depends on the chain, so all L x 128 terms are formed HERE, before the layer loop and outside its weight
+      // schedule: thread (o = tid & 127, lp = tid >> 7) takes the layers l = lp (mod 2), row o over the 64 context
+      // channels (generic context section: per layer Wt[k][o: f | g] then bias[2C]).
+      const int lp = tid >> 7;
+      for (int l = lp; l < L; l += 2) {
+        const float *wc = a.wctx + (size_t)l * (2 * C * C + 2 * C);
+        float acc[4] = {wc[2 * C * C + o], 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < C; k += 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(wc[(size_t)(k + e) * 2 * C + o], cvec[k + e], acc[e]);
+        }
+        pctx[l * 128 + o] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      }
+      lds_barrier();
+    }
     if (tid < 64) xcat[tid] = pastAll[tid];
     lds_barrier();
 
@@ -374,8 +395,12 @@ __global__ __launch_bounds__(256, 1) void gen_stream64_kernel(GenArgs a) {
       }
       lds_barrier();
       if (tid < 64) {
-        const float f = pfg[tid] + pfg[128 + tid];
-        const float g = pfg[64 + tid] + pfg[192 + tid];
+        float f = pfg[tid] + pfg[128 + tid];
+        float g = pfg[64 + tid] + pfg[192 + tid];
+        if (a.ctx_tm) {
+          f += pctx[l * 128 + tid];
+          g += pctx[l * 128 + 64 + tid];
+        }
         zbuf[tid] = gate(f, g);
         // queue push: this layer's input at time t replaces the one popped
         const int d = 1 << (l % a.layer_size);
@@ -872,7 +897,7 @@ int mvn_gen_pack_weights(const mvn_dims *dims, int variant, const mvn_params *p,
     if (rc || !has_ctx) return rc;
     return mvn::pipe_pack_ctx(dims, p, ctx_section, stream);  // same per-layer layout as PIPE
   }
-  if (has_ctx && variant == MVN_GEN_GENERIC) {
+  if (has_ctx && (variant == MVN_GEN_GENERIC || variant == MVN_GEN_STREAM)) {  // (STREAM reads the generic section)
     const int Cc = dims->residual_channels, n = 2 * Cc * Cc + 2 * Cc;
     for (int l = 0; l < mvn::n_layers(dims); ++l)
       hipLaunchKernelGGL(mvn::pack_ctx_generic_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
@@ -955,10 +980,6 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
   a.ctx_tm = context_tm;
   a.ctx_stride_b = (long long)n_total * dims->residual_channels;
   a.wctx = packed + mvn::gen_base_floats(dims, variant);
-  if (context_tm && variant == MVN_GEN_STREAM) {
-    mvn::set_error("local conditioning is built for the GENERIC, PIPE and FOLD generator variants only");
-    return MVN_ERR_UNSUPPORTED;
-  }
   if (variant == MVN_GEN_PIPE || variant == MVN_GEN_PIPE_F16 || variant == MVN_GEN_FOLD) {
     float *hand = state + (size_t)batch * a.state_per_seq;
     const size_t total = mvn::hand_total_floats(dims, batch), soff = mvn::hand_status_offset(dims, batch);
@@ -969,7 +990,11 @@ int mvn_generate(const mvn_dims *dims, int variant, const float *packed, float *
   if (variant == MVN_GEN_STREAM) {
     const size_t lds =
         sizeof(float) * ((size_t)mvn::s64::EMB_FLOATS + 128 + 256 + 64 + 256 + 64 + 256 + 32 + 8 +
-                         (size_t)a.L * 64);
+                         (size_t)a.L * 64 + (context_tm ? (size_t)a.L * 128 + 64 : 0));
+    if (lds > 160 * 1024) {
+      mvn::set_error("STREAM variant: %d conditioned layers do not fit a CU's LDS", a.L);
+      return MVN_ERR_UNSUPPORTED;
+    }
     int rc = mvn::ensure_max_dynamic_lds((const void *)mvn::gen_stream64_kernel,
                                          "hipFuncSetAttribute(gen_stream64)");
     if (rc) return rc;

@@ -191,8 +191,7 @@ class RingGenerator:
         with torch.cuda.device(self.device):
             self.variant = N.check(self.lib.mvn_gen_variant(self.dims, variant, self.batch),
                                    "mvn_gen_variant")
-            if context is not None and self.variant == N.GEN_STREAM:
-                self.variant = N.GEN_GENERIC  # conditioning: GENERIC and PIPE variants only
+            # (r4: STREAM takes local conditioning too -- the context terms of all layers are formed at the top of a step)
         self.context = None      # (B, C, >= n_total) upsampled video as given
         self.context_tm = None   # (B, n_total, C) time-major copy the kernels read
         if context is not None:
@@ -352,7 +351,62 @@ _PIPELINED_US = {(64, N.GEN_FOLD): (14.7, 15.3, 2.64, 8), (64, N.GEN_PIPE): (17.
 _FOLD_CROSS_US = (16.4, 2.95)   # FOLD on all 23 pipelines: latency of a cross-XCD pipeline, us per turn
 # ... and of the best kernel that takes EVERY sequence in one launch; keys: (C, conditioned):
 # STREAM at C=64 without conditioning, GENERIC otherwise
-_T_SINGLE_US = {(64, False): 78.0, (64, True): 290.0, (128, False): 490.0, (128, True): 490.0}
+# (r4: STREAM takes conditioning too -- (64, True) was GENERIC's 290 us)
+_T_SINGLE_US = {(64, False): 78.0, (64, True): 100.0, (128, False): 490.0, (128, True): 490.0}
+
+# The tables above were measured on ONE MI355X; boxes of a pool differ by up to 15 % and a cross-over between "k
+# pipelined launches" and "one launch of the kernel that holds everything" moves with the RATIO of the two kernel
+# families on the device at hand.  So the tables are only the SHAPE of the model: at first use per (device, C) the two
+# families are timed once each on this device (`calibrate`) and the tables are scaled by measured / tabulated.
+_CALIBRATION: dict = {}
+
+
+def calibrate(dims, device=None, steps: int = 192) -> dict:
+    """{"pipelined": measured / tabulated step time of one round of the pipelined kernel AUTO prefers, "single": the same
+    for the one-launch kernel (STREAM or GENERIC)}, timed ONCE per (device, C, K, Q, L) with HIP events on synthetic weights
+    (~0.1 s at config 2) and cached.  ``auto_plan`` multiplies its tables by these."""
+    lib = N.lib()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (device.index, dims.layer_size, dims.stack_size, dims.input_channels, dims.residual_channels, dims.skip_channels)
+    hit = _CALIBRATION.get(key)
+    if hit is not None:
+        return hit
+    from .utils.weights import make_state_dict, synthetic_indices
+    cfg = dict(layer_size=dims.layer_size, stack_size=dims.stack_size, input_channels=dims.input_channels,
+               residual_channels=dims.residual_channels, skip_channels=dims.skip_channels)
+    C = dims.residual_channels
+    out = {"pipelined": 1.0, "single": 1.0}
+    with torch.cuda.device(device):
+        sd = {k: v.to(device) for k, v in make_state_dict(**cfg, seed=0).items()}
+        rf = int(lib.mvn_receptive_fields(dims))
+        one_launch = N.GEN_STREAM if lib.mvn_gen_variant(dims, N.GEN_STREAM, 1) == N.GEN_STREAM else N.GEN_GENERIC
+        for kind, variant in (("pipelined", next((v for v in (N.GEN_FOLD, N.GEN_PIPE) if (C, v) in _PIPELINED_US and
+                                                  lib.mvn_gen_variant(dims, v, 1) == v), None)),
+                              ("single", one_launch)):
+            if variant is None or (kind == "single" and (C, False) not in _T_SINGLE_US):
+                continue
+            n = max(1, lib.mvn_gen_launch_pipelines(dims, variant, 1 << 20)) if kind == "pipelined" else 4
+            if kind == "pipelined":  # one round on the pipelines that sit inside one XCD (FOLD: 16 of the 23)
+                n = max(1, lib.mvn_gen_launch_pipelines(dims, variant, min(n, 16)))
+            g = RingGenerator(**cfg, state_dict=sd, batch=n, n_total=rf + 2 * steps + 2, device=device, variant=variant)
+            g.prime(synthetic_indices(n, rf, dims.input_channels, 1234).to(device))
+            g.advance(steps)  # warm-up (code objects, weights into place)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            g.advance(steps)
+            ev[1].record()
+            ev[1].synchronize()
+            try:
+                g.check_errors()
+            except PipeHandoffTimeout:
+                continue  # (a starved launch says nothing about the device: keep the table)
+            us = ev[0].elapsed_time(ev[1]) * 1e3 / steps
+            table = _PIPELINED_US[(C, variant)][0] if kind == "pipelined" else (
+                _T_SINGLE_US[(C, False)] if variant == N.GEN_STREAM or C != 64 else 290.0)
+            out[kind] = us / table
+            out[kind + "_us_per_step"] = us
+    _CALIBRATION[key] = out
+    return out
 
 
 def _launch_step_us(dims, variant: int, n: int):
@@ -372,8 +426,12 @@ def _launch_step_us(dims, variant: int, n: int):
     return t_one if rounds <= 1 else max(t_multi, t_turn * rounds)
 
 
-def auto_plan(dims, batch: int, has_context: bool):
-    """What MVN_GEN_AUTO means at the Python level for ``batch`` sequences: returns
+def auto_plan(dims, batch: int, has_context: bool, calibration=None):
+    """``calibration``: ``{"pipelined": f, "single": f}`` scale factors of the two kernel families on the device at hand
+    (default: ``calibrate(dims)``, measured once at first need -- only batches beyond ONE pipelined launch consult it;
+    pass ``{"pipelined": 1.0, "single": 1.0}`` for the tables as measured on the reference box).
+
+    What MVN_GEN_AUTO means at the Python level for ``batch`` sequences: returns
     ``("single", 0, variant)`` for one launch or ``("grouped", group, variant)`` for groups of
     ``group`` sequences taking turns on the pipelines of a pipelined variant.
 
@@ -401,7 +459,8 @@ def auto_plan(dims, batch: int, has_context: bool):
     cost, k, group, variant = best
     if k == 1:
         return "single", 0, variant
-    if cost < _T_SINGLE_US.get((C, bool(has_context)), 0.0):
+    cal = calibration if calibration is not None else calibrate(dims)
+    if cost * cal.get("pipelined", 1.0) < _T_SINGLE_US.get((C, bool(has_context)), 0.0) * cal.get("single", 1.0):
         return "grouped", group, variant
     return "single", 0, single  # the kernel the C library's AUTO names: every sequence in one launch
 

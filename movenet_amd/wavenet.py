@@ -248,8 +248,9 @@ class WaveNet(nn.Module):
             # CUs: rerun THIS call (same prompt, same seed) on a kernel without hand-offs
             with torch.cuda.device(audio.device):
                 lib = N.lib()
-                fallback = N.GEN_STREAM if (context is None and lib.mvn_gen_variant(
-                    self._dims, N.GEN_STREAM, idx.shape[0]) == N.GEN_STREAM) else N.GEN_GENERIC
+                # (STREAM: C = K = 64, any batch in one launch, conditioned or not -- r4; GENERIC otherwise)
+                fallback = N.GEN_STREAM if lib.mvn_gen_variant(
+                    self._dims, N.GEN_STREAM, idx.shape[0]) == N.GEN_STREAM else N.GEN_GENERIC
             self.last_generate_fallback = fallback
             name = {N.GEN_STREAM: "STREAM", N.GEN_GENERIC: "GENERIC"}[fallback]
             print(f"[movenet_amd] generate: pipelined kernel (variant {variant}) timed out waiting for a "

@@ -549,8 +549,41 @@ def test_pipe_status_word_is_sticky_and_checked(variant):
     assert torch.equal(g.samples, ref.samples)
 
 
-@pytest.mark.parametrize("B", [3, 20])
-def test_model_generate_reruns_on_pipe_timeout(monkeypatch, B):
+def test_conditioned_stream_matches_generic_and_fold():
+    """r4: gen_stream64_kernel with local conditioning (the context terms of all layers formed at the top of a step):
+    greedy samples bit-equal to GENERIC and FOLD on a conditioned run, teacher-forced logits within 2e-5 of GENERIC's."""
+    from movenet_amd.utils.weights import make_state_dict
+    sd = make_state_dict(**CFG2, seed=1, gain=2.0, head_gain=6.0)
+    rf, B, n_new = 3072, 3, 40
+    prompt = synthetic_indices(B, rf, 256, 5)
+    ctx = torch.from_numpy(np.random.default_rng(9).standard_normal((B, 64, rf + n_new)).astype(np.float32)).to(DEV)
+    runs = {}
+    for variant in (N.GEN_GENERIC, N.GEN_STREAM, N.GEN_FOLD):
+        from movenet_amd.generation import RingGenerator
+        g = RingGenerator(**CFG2, state_dict={k: v.to(DEV) for k, v in sd.items()}, batch=B, n_total=rf + n_new, device=DEV,
+                          variant=variant, temperature=0.0, context=ctx)
+        assert g.variant == variant
+        g.prime(prompt.to(DEV))
+        g.advance(n_new)
+        g.check_errors()
+        samples = g.samples.clone()
+        _, logits = g.teacher_forced(samples, logits_t0=rf)
+        runs[variant] = (samples, logits)
+    ref_s, ref_l = runs[N.GEN_GENERIC]
+    for variant in (N.GEN_STREAM, N.GEN_FOLD):
+        assert torch.equal(runs[variant][0], ref_s), variant
+        err = float((runs[variant][1] - ref_l).abs().max() / ref_l.abs().max())
+        assert err < 2e-5, (variant, err)
+    # conditioning matters on this run: without it the samples differ
+    g0 = RingGenerator(**CFG2, state_dict={k: v.to(DEV) for k, v in sd.items() if ".context_conv_" not in k}, batch=B,
+                       n_total=rf + n_new, device=DEV, variant=N.GEN_STREAM, temperature=0.0)
+    g0.prime(prompt.to(DEV))
+    g0.advance(n_new)
+    assert not torch.equal(g0.samples, ref_s)
+
+
+@pytest.mark.parametrize("B,with_video", [(3, False), (20, False), (3, True)])
+def test_model_generate_reruns_on_pipe_timeout(monkeypatch, B, with_video):
     """WaveNet.generate never returns unchecked samples: with the PIPE status word raised
     during the call it reruns the same call on STREAM in the same process.  B = 20 is a MULTI
     launch (16 pipelines, the first four serving two sequences in turn): the starved path with
@@ -564,6 +597,14 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch, B):
     model.to(DEV)
     rf, n_new = 3072, 20
     prompt = one_hot(synthetic_indices(B, rf, 256, 8), 256).to(DEV)
+    video = None
+    if with_video:  # (r4: a conditioned call is rerun on STREAM too, not on GENERIC; Q8: 4 frames <-> 4000 samples)
+        import movenet_amd.wavenet as W
+        monkeypatch.setattr(W, "MAX_AUDIO_FRAMES", 4000)
+        monkeypatch.setattr(W, "MAX_VIDEO_FRAMES", 4)
+        video = torch.from_numpy(np.random.default_rng(3).random((B, 4, 64, 64, 1), dtype=np.float32)).to(DEV)
+    _generate = model.generate
+    model.generate = lambda p, **kw: _generate(p, video, **kw)
     want = model.generate(prompt, n_samples=rf + n_new, temperature=0.0)
     assert model.last_generate_fallback is None
     assert N.lib().mvn_gen_launch_is_cooperative() == 1  # no profiler attached: the runtime guarantees co-residency
@@ -589,7 +630,13 @@ def test_model_generate_reruns_on_pipe_timeout(monkeypatch, B):
 
 
 def test_auto_plan_cost_based():
-    from movenet_amd.generation import auto_plan
+    from movenet_amd.generation import auto_plan as _plan, calibrate
+    # the tables as measured on the reference box (the per-device calibration is checked at the end)
+    TABLE = {"pipelined": 1.0, "single": 1.0}
+
+    def auto_plan(d, n, c):
+        return _plan(d, n, c, calibration=TABLE)
+
     d2, d5 = N.make_dims(10, 3, 256, 64, 64), N.make_dims(10, 6, 256, 128, 128)
     for n in (1, 16, 20, 32, 64, 128, 161, 184):                       # one FOLD launch: 16 pipelines, 23 beyond 80 sequences
         assert auto_plan(d2, n, False) == ("single", 0, N.GEN_FOLD)
@@ -599,12 +646,19 @@ def test_auto_plan_cost_based():
     assert auto_plan(d2, 400, False) == ("grouped", 134, N.GEN_FOLD)  # 3 x 17.7 us
     assert auto_plan(d2, 500, False) == ("grouped", 167, N.GEN_FOLD)  # 3 x 23.6 us < 78 us
     assert auto_plan(d2, 600, False) == ("single", 0, N.GEN_STREAM)   # 4 x 20.7 us > 78 us
-    assert auto_plan(d2, 600, True) == ("grouped", 150, N.GEN_FOLD)   # no conditioned STREAM kernel
+    assert auto_plan(d2, 600, True) == ("grouped", 150, N.GEN_FOLD)   # 4 x 20.7 us < 100 us (conditioned STREAM, r4)
+    assert auto_plan(d2, 800, True) == ("single", 0, N.GEN_STREAM)    # 5 x 21 us > 100 us
     for n in (1, 4, 5, 16, 24, 64):                                    # one PIPE launch, 1 - 16 rounds: 73 us
         assert auto_plan(d5, n, False) == ("single", 0, N.GEN_PIPE)
     assert auto_plan(d5, 65, False) == ("grouped", 33, N.GEN_PIPE)    # 2 x 73 us < 490 us
     assert auto_plan(d5, 384, False) == ("grouped", 64, N.GEN_PIPE)   # 6 x 73 us
     assert auto_plan(d5, 385, False) == ("single", 0, N.GEN_GENERIC)  # 7 x 73 us > 490 us
+    # per-device calibration: both kernel families timed once on THIS device, within a factor of two of the tables,
+    # cached, and what auto_plan uses by default
+    cal = calibrate(d2)
+    assert 0.5 < cal["pipelined"] < 2.0 and 0.5 < cal["single"] < 2.0, cal
+    assert calibrate(d2) is cal
+    assert _plan(d2, 256, False)[0] == "grouped"
 
 
 @pytest.mark.parametrize("layer_size,stack_size", [(1, 1), (2, 1), (4, 1), (5, 2), (10, 2), (7, 3)])
