@@ -74,6 +74,9 @@ typedef struct mvn_params {
 } mvn_params;
 
 int mvn_abi_version(void);
+/* The library's A/B switches (MOVENET_HIP_* environment variables selecting kernel forms: cross-checks in the
+ * tests, same-box comparisons) are parsed once per process at first use; this parses them again. */
+int mvn_reload_switches(void);
 const char *mvn_last_error(void);
 
 /* movenet/wavenet.py:125-134 (receptive_fields) and :136-147

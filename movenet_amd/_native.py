@@ -93,6 +93,7 @@ class VideoParams(C.Structure):  # also used for mvn_video_grads (same layout)
 # name -> (restype, argtypes); tests/test_capi.py checks the header against this
 SIGNATURES = {
     "mvn_abi_version": (C.c_int, []),
+    "mvn_reload_switches": (C.c_int, []),
     "mvn_last_error": (C.c_char_p, []),
     "mvn_receptive_fields": (C.c_int, [C.POINTER(Dims)]),
     "mvn_output_size": (C.c_int, [C.POINTER(Dims), C.c_int]),

@@ -8,6 +8,12 @@
 
 #include "movenet_hip.h"
 
+// Timing / diagnostic builds only (python -m movenet_amd.csrc.build --stamps --exp=N; the fused layer backward's
+// 71-74 and 76, fused_bwd_l.h): 0 = the product, which is all the tracked library ever is.
+#ifndef MVN_EXP
+#define MVN_EXP 0
+#endif
+
 namespace mvn {
 
 constexpr int kWave = 64;
@@ -27,6 +33,26 @@ int validate_dims(const mvn_dims *d);
 // (kernel, device): hipFuncSetAttribute applies to the current device's copy of the code
 // object, so a per-process flag would leave a second device at the 64 KiB default.
 int ensure_max_dynamic_lds(const void *kernel, const char *what);
+
+// The A/B switches of the full-sequence path (cross-checks between kernel forms in the tests, same-box comparisons):
+// parsed from the environment ONCE per process, at first use -- a forward call used to make ~20 getenv calls, several
+// inside its per-layer loop.  mvn_reload_switches() parses them again (tests that change a switch inside one process;
+// movenet_amd.ops calls it before each pass when MOVENET_DEBUG_GUARD is set, which the test suite does).
+struct Switches {
+  int forward_tile;            // MOVENET_HIP_FORWARD_TILE: 0 (strip kernel), 32 or 64 (the tile kernels)
+  bool head_f32;               // MOVENET_HIP_HEAD_MFMA=f32: the head's fp32 kernels
+  bool forward_f32;            // MOVENET_HIP_FORWARD_MFMA=f32: the fp32-MFMA strip forward
+  bool wgrad_f32;              // MOVENET_HIP_WGRAD_MFMA=f32
+  bool no_fused_forward;       // MOVENET_HIP_NO_FUSED_FORWARD=1
+  bool no_persistent_forward;  // MOVENET_HIP_NO_PERSISTENT_FORWARD=1
+  bool no_dense_strip;         // MOVENET_HIP_NO_DENSE_STRIP=1
+  bool no_side_stream;         // MOVENET_HIP_NO_SIDE_STREAM=1
+  bool no_fused_backward;      // MOVENET_HIP_NO_FUSED_BACKWARD=1: the generic two-kernel forms
+  bool bwd_split;              // MOVENET_HIP_BWD_FORM=split: the two fused halves of r2 / r3
+  bool embed_scalar;           // MOVENET_HIP_EMBED_GRAD=scalar
+};
+const Switches &switches();
+void parse_switches();
 
 // ---- device side --------------------------------------------------------
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }

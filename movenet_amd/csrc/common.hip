@@ -16,6 +16,33 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+static Switches g_switches;
+static std::once_flag g_switches_once;
+void parse_switches() {
+  auto is = [](const char *name, char c) {
+    const char *e = getenv(name);
+    return e && e[0] == c;
+  };
+  Switches w;
+  const char *t = getenv("MOVENET_HIP_FORWARD_TILE");
+  w.forward_tile = (t && t[0] == '6') ? 64 : (t && t[0] == '3') ? 32 : (t && t[0]) ? 32 : 0;
+  w.head_f32 = is("MOVENET_HIP_HEAD_MFMA", 'f');
+  w.forward_f32 = is("MOVENET_HIP_FORWARD_MFMA", 'f');
+  w.wgrad_f32 = is("MOVENET_HIP_WGRAD_MFMA", 'f');
+  w.no_fused_forward = is("MOVENET_HIP_NO_FUSED_FORWARD", '1');
+  w.no_persistent_forward = is("MOVENET_HIP_NO_PERSISTENT_FORWARD", '1');
+  w.no_dense_strip = is("MOVENET_HIP_NO_DENSE_STRIP", '1');
+  w.no_side_stream = is("MOVENET_HIP_NO_SIDE_STREAM", '1');
+  w.no_fused_backward = is("MOVENET_HIP_NO_FUSED_BACKWARD", '1');
+  w.bwd_split = is("MOVENET_HIP_BWD_FORM", 's');
+  w.embed_scalar = is("MOVENET_HIP_EMBED_GRAD", 's');
+  g_switches = w;
+}
+const Switches &switches() {
+  std::call_once(g_switches_once, parse_switches);
+  return g_switches;
+}
+
 int check_hip(hipError_t e, const char *what) {
   if (e == hipSuccess) return MVN_OK;
   set_error("%s: %s", what, hipGetErrorString(e));
@@ -379,6 +406,11 @@ int mvn_mu_law_decode(const int32_t *index, float *x, size_t n, int classes, voi
   hipLaunchKernelGGL(mvn::mu_law_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, index, x, n, classes);
   return mvn::check_hip(hipGetLastError(), "mu_law_decode");
+}
+
+int mvn_reload_switches(void) {
+  mvn::parse_switches();
+  return MVN_OK;
 }
 
 int mvn_abi_version(void) { return MVN_ABI_VERSION; }

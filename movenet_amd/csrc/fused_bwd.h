@@ -76,15 +76,6 @@ __device__ __forceinline__ void fb_store16(f4 x, __amdgpu_buffer_rsrc_t r, int v
                                          r, voff, soff, 0);
 }
 
-#ifndef MVN_BWD_DX_BF3
-#define MVN_BWD_DX_BF3 (MVN_EXP != 61 && MVN_EXP != 63)  // (build 63: the dx products of the second half on fp32 MFMAs)
-#endif
-#ifndef MVN_BWD_WG_BF3
-#define MVN_BWD_WG_BF3 (MVN_EXP != 61)  // (build 61: the weight-gradient products on fp32 MFMAs, right results)
-#endif
-#ifndef MVN_EXP
-#define MVN_EXP 0  // timing builds of the first half (wrong results): 51 no dfg stores, 52 no global loads after a
-#endif             // workgroup's first tile, 53 both
 __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, int chunks_per_b, int chunk_t,
                                                               float *__restrict__ bias_part,
                                                               float *__restrict__ part) {
@@ -199,11 +190,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
   __syncthreads();
   for (int t0 = tb; t0 < te; t0 += TT) {
     const bool more = t0 + TT < te;
-#if MVN_EXP == 52 || MVN_EXP == 53
-    if (more && a.t_end < 0) gload(t0 + TT);
-#else
     if (more) gload(t0 + TT);  // the next tile's loads fly under this tile's MFMAs
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // ---- dz' (32 t x 32 c) = sum over the 128 rows of the tile
     f32x16 accd;
@@ -260,10 +247,6 @@ __global__ __launch_bounds__(256, 2) void bwd_dz_wgrs64_kernel(FusedBwdAArgs a, 
       // whole-row float4 stores: rows 16 p + srow, columns t0 + st .. +3, inside [t_begin, te)
       const int t = t0 + st;
       float *base = a.dfg.p + (size_t)b * a.dfg.sb + t;
-#if MVN_EXP == 51 || MVN_EXP == 53
-      if (a.t_end >= 0) {
-      } else
-#endif
       if (t >= a.t_begin && t + 3 < te) {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
@@ -500,7 +483,6 @@ __global__ __launch_bounds__(256, 2) void bwd_dctx_wgctx64_kernel(FusedBwdCArgs 
     for (int kk = 0; kk < C; ++kk)
       accd = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + lh][32 * wt + li], wreg[kk], accd, 0, 0, 0);
     // ---- weight gradient: (64 x 32) += dfg (64 x 64 t) ctx^T
-#if MVN_BWD_WG_BF3
 #pragma unroll
     for (int G = 0; G < TT / 16; ++G) {
       u32x4 ah[2], am[2], al[2], ch, cm, cl;
@@ -519,20 +501,6 @@ __global__ __launch_bounds__(256, 2) void bwd_dctx_wgctx64_kernel(FusedBwdCArgs 
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) bf3_mfma6r(accw[mi], ah[mi], am[mi], al[mi], ch, cm, cl);
     }
-#else
-#pragma unroll
-    for (int g = 0; g < TT / 8; ++g) {
-      f4 av[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) av[mi] = *(const f4 *)&As[64 * wm + 32 * mi + li][8 * g + h4];
-      const f4 cv = *(const f4 *)&Cx[32 * wn + li][8 * g + h4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          accw[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[mi], j), f4_get(cv, j), accw[mi], 0, 0, 0);
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // ---- this lane owns dctx of channel 32 wc + li at t = 32 wt + 8 q + 4 lh + e: add in LDS
 #pragma unroll
@@ -643,7 +611,6 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
   const int tb = (a.t_out0 & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
   const bool has_dxo = a.dxo.p != nullptr;
 
-#if MVN_BWD_DX_BF3
   // ---- dx on the bf16 matrix cores (r3): wave -> (tap half, K half kh, 32-channel block wc); it forms BOTH 32-step
   // blocks of the tile over its 64 of the tap's 128 rows, so that its weights are 4 k-steps x 3 planes = 48
   // registers (all 128 rows would be 96; as fp32 MFMA operands they were 64) and the two K halves meet in the
@@ -661,17 +628,6 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     }
     bf3_split8(wv, wp[j][0], wp[j][1], wp[j][2]);
   }
-#else
-  // ---- dx: wave -> (tap half, 32 u x 32 c block); B operand W_tap[o][32 wc + li], o = 2 kk + lh
-  const int half = wave >> 2, wt = (wave >> 1) & 1, wc = wave & 1;
-  float wreg[C];
-#pragma unroll
-  for (int kk = 0; kk < C; ++kk) {
-    const int o = 2 * kk + lh;
-    const float *src = o < C ? a.wf : a.wg;
-    wreg[kk] = src[((size_t)(o & (C - 1)) * C + 32 * wc + li) * 2 + (half ? 0 : 1)];
-  }
-#endif
   // ---- weight gradient: wave -> rows [32 (wave >> 1), +32), columns [64 (wave & 1), +64)
   const int wm = wave >> 1, wn = wave & 1;
   f32x16 accw[2];
@@ -771,7 +727,6 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
     // steps of 8 + 8 MFMAs.  The LDS operands of step g + 1 are requested BEFORE the MFMAs of
     // step g (two statically named register sets): left to the scheduler every pair of MFMAs
     // waited out the ds_read issued right in front of it.
-#if MVN_BWD_DX_BF3
     f32x16 accd2[2];
 #pragma unroll
     for (int ub = 0; ub < 2; ++ub)
@@ -816,94 +771,8 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#else
-    f32x16 accd;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
-#if MVN_BWD_WG_BF3
-    {
-      // r3: the weight-gradient half of the tile's products on the bf16 matrix cores (bf3.h): per 16 time
-      // steps the wave reads its three row operands eight steps per lane (two ds_read_b128 each), splits them into
-      // three bf16 planes (132 vector instructions) and issues 12 bf16 MFMAs instead of 16 fp32 ones; the dx half
-      // keeps its fp32 MFMAs (its operand is read ACROSS the tile's rows, and its 64 weights per lane would be 96
-      // registers as planes: the kernel has 6 to spare).
-      float (*src)[LD] = half ? A2 : As;
-      float dv[2][8];
-      auto fetch_dv = [&](int g, int S) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dv[S][i] = src[2 * (8 * g + i) + lh][32 * wt + li];
-      };
-      fetch_dv(0, 0);
-#pragma unroll
-      for (int G = 0; G < TT / 16; ++G) {
-        const f4 a0 = *(const f4 *)&As[32 * wm + li][16 * G + 2 * h4], a1 = *(const f4 *)&As[32 * wm + li][16 * G + 2 * h4 + 4];
-        f4 x0[2], x1[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          x0[ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][16 * G + 2 * h4];
-          x1[ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][16 * G + 2 * h4 + 4];
-        }
-        u32x4 ah, am, al, bh[2], bm[2], bl[2];
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          const int g = 2 * G + gg, S = g & 1;
-          if (g + 1 < TT / 8) fetch_dv(g + 1, S ^ 1);
-          if (spread) gload_part(t0 + TT, g);
-          __builtin_amdgcn_sched_barrier(0);
-          if (gg == 0) {
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            bf3_split8(av, ah, am, al);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const float xv[8] = {x0[ni].x, x0[ni].y, x0[ni].z, x0[ni].w, x1[ni].x, x1[ni].y, x1[ni].z, x1[ni].w};
-              bf3_split8(xv, bh[ni], bm[ni], bl[ni]);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            accd = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[S][i], wreg[8 * g + i], accd, 0, 0, 0);
-          if (gg == 1) {
-            bf3_mfma6r(accw[0], ah, am, al, bh[0], bm[0], bl[0]);
-            bf3_mfma6r(accw[1], ah, am, al, bh[1], bm[1], bl[1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-#else
-    {
-      float (*src)[LD] = half ? A2 : As;
-      float dv[2][8];
-      f4 av[2], xv[2][2];
-      auto fetch = [&](int g, int S) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dv[S][i] = src[2 * (8 * g + i) + lh][32 * wt + li];
-        av[S] = *(const f4 *)&As[32 * wm + li][8 * g + h4];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) xv[S][ni] = *(const f4 *)&Xs[64 * wn + 32 * ni + li][8 * g + h4];
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int g = 0; g < TT / 8; ++g) {
-        const int S = g & 1;
-        if (g + 1 < TT / 8) fetch(g + 1, S ^ 1);
-        if (spread) gload_part(t0 + TT, g);  // (two parts per step in the first four steps: 182 against 175 us)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[S], j), f4_get(xv[S][0], j), accw[0], 0, 0, 0);
-          accd = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[S][2 * j], wreg[8 * g + 2 * j], accd, 0, 0, 0);
-          accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(av[S], j), f4_get(xv[S][1], j), accw[1], 0, 0, 0);
-          accd = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[S][2 * j + 1], wreg[8 * g + 2 * j + 1], accd, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#endif
-#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores (see the first half)
-#if MVN_BWD_DX_BF3
     // the two K halves of a tap half meet in the staging tile: kh = 0 stores, kh = 1 adds behind a barrier (a lane
     // owns the same elements in both)
     if (kh == 0) {
@@ -926,13 +795,6 @@ __global__ __launch_bounds__(512, 1) void bwd_dx_wgfg64_kernel(FusedBwdBArgs a, 
         }
     }
     __syncthreads();  // the dx halves are staged AND every wave has read the operand tiles
-#else
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *(f4 *)&St[64 * half + 32 * wc + li][32 * wt + 8 * q + h4] =
-          f4{accd[4 * q], accd[4 * q + 1], accd[4 * q + 2], accd[4 * q + 3]};
-    __syncthreads();  // the dx halves are staged AND every wave has read the operand tiles
-#endif
     {
       // rows srow + 32 p (p < 2), columns t0 + st .. +3 inside [t_out0, te)
       const int t = t0 + st;

@@ -305,9 +305,6 @@ __global__ __launch_bounds__(256 * NTB, NTB == 1 ? 2 : 1) void fused_layer64p_ke
 // ----------------------------------------------------------------------------------------
 // HAS_CTX: the conditioned layer -- the context is a third K block of the first product (96 KB of
 // f|g weights), its 32 registers are the ones the unconditioned kernel uses to fetch x(t) a strip ahead.
-#ifndef MVN_EXP
-#define MVN_EXP 0  // timing experiments (wrong results): 11 no x(t-d) loads after a wave's first strip, 12 + no skip
-#endif             // loads, 13 no stores, 14 = 12 + 13
 // Strips start at multiples of 32 columns of the absolute time axis (rows are 256-byte aligned: every
 // 128-byte row segment a store instruction writes is ONE cache line, not two halves: 148.6 -> 142.4 us
 // per layer), and tanh / sigmoid -- written once, read by the backward pass much later -- leave with
@@ -322,11 +319,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5;
-#if MVN_EXP == 26  // timing build: the weight staging only, no strip
-  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.d < 0 ? tb + chunk_t : tb;
-#else
   const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
-#endif
   const int skip_lo = max(a.t_begin, a.t_skip0);
   // ---- weights into LDS: [block][k-step / 4][lane][k-step % 4].  The loop runs over the SOURCE
   // elements (coalesced reads of the (out, in, tap) / (out, in) tensors) and scatters into LDS.
@@ -375,11 +368,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
   const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ctx.p + (size_t)b * a.ctx.sb), 0, 0x7FFFFFFF, RSRC);
-#if MVN_EXP == 13 || MVN_EXP == 14
-  const bool st_ok = a.d < 0;  // (never: the stores stay in the code, none is executed)
-#else
   constexpr bool st_ok = true;
-#endif
   const bool save = st_ok && a.th.p != nullptr, has_out = st_ok && a.xout.p != nullptr;
   int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld, cld4 = 4 * a.ctx.ld;
   // (row offsets = row * ld are re-formed where they are used, behind a fence on ld: hoisted out of
@@ -446,12 +435,6 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     // ---- x(t - d) of channel kc(j) + 4 lh: B operand of k-steps 0..31; later the skip accumulator's old values
     float xa0[32];
     FS_FENCE(xld4);
-#if MVN_EXP == 11 || MVN_EXP == 12 || MVN_EXP == 14
-    if (t0 != tb + 32 * wave) {
-#pragma unroll
-      for (int j = 0; j < 32; ++j) xa0[j] = xb1[j] * 0.5f;
-    } else
-#endif
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
@@ -499,11 +482,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_kernel(FusedFwdPArgs a,
     // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's
     // x(t), both under the MFMAs below
     FS_FENCE(skld4);
-#if MVN_EXP == 12 || MVN_EXP == 14
-    if (false) {
-#else
     if (!a.first_layer) {
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -625,11 +604,7 @@ __global__ __launch_bounds__(512, 1) void dense_strip_kernel(DenseStripArgs a, i
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int m_base = blockIdx.y * M;
   const int li = lane & 31, lh = lane >> 5;
-#if MVN_EXP == 26  // timing build: the weight staging only, no strip
-  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.ldw < 0 ? tb + chunk_t : tb;
-#else
   const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
-#endif
   for (int r = tid; r < K * M; r += 512) {  // source order: coalesced
     const int m = TRANSPOSED ? r % M : r / K, k = TRANSPOSED ? r / M : r % K;
     const int kk = k >> 1;
@@ -734,9 +709,9 @@ static int launch_fused_layer64p_t(const FusedFwdPArgs &a, int batch, hipStream_
 // The strip kernel is the default; MOVENET_HIP_FORWARD_TILE=32 / 64 select the tile kernels (A/B, tests)
 static int launch_fused_layer64p(const FusedFwdPArgs &a, int batch, hipStream_t s) {
   if (a.ctx.p) return launch_fused_layer64s(a, batch, s);  // conditioned: the strip kernel only (the caller checks the row length)
-  const char *e = getenv("MOVENET_HIP_FORWARD_TILE");
-  if (e && e[0] == '6') return launch_fused_layer64p_t<2>(a, batch, s);
-  if (e && e[0] == '3') return launch_fused_layer64p_t<1>(a, batch, s);
+  const int tile = switches().forward_tile;
+  if (tile == 64) return launch_fused_layer64p_t<2>(a, batch, s);
+  if (tile == 32) return launch_fused_layer64p_t<1>(a, batch, s);
   // (the strip kernel's buffer resources span 2 GB from a sequence's base: rows of more than 4 M
   // columns -- 25 x the reference's MAX_AUDIO_FRAMES -- go to the tile kernel)
   if (a.xin.ld > (1 << 22) || a.skip.ld > (1 << 22)) return launch_fused_layer64p_t<1>(a, batch, s);

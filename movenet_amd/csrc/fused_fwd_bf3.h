@@ -32,7 +32,7 @@ __device__ __forceinline__ void bf3_mfma6(f32x16 &acc, unsigned wa, const u32x4 
   const u32x4 ah = *(const lds_u4 *)(uintptr_t)wa;
   const u32x4 am = *(const lds_u4 *)(uintptr_t)(wa + 1024u);
   const u32x4 al = *(const lds_u4 *)(uintptr_t)(wa + 2048u);
-#if MVN_EXP == 25 || MVN_EXP == 74
+#if MVN_EXP == 74  // (timing build of fused_bwd_l.h: no MFMAs)
 #define BF3_MF(a_, b_) acc[0] += __uint_as_float(a_[0] ^ b_[0])
 #else
 #define BF3_MF(a_, b_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc, 0, 0, 0)
@@ -53,9 +53,6 @@ __device__ __forceinline__ void bf3_mfma6(f32x16 &acc, unsigned wa, const u32x4 
 // groups pin that order (the compiler's own put each read right in front of its MFMA: 44 % of the wave cycles
 // were waits on LDS, SQ_WAIT_ANY of the build without global accesses).
 //   BVAL: expression of (ks_, e_) = value e_ of k-step ks_'s eight
-#ifndef MVN_BF3_PIPELINED
-#define MVN_BF3_PIPELINED (MVN_EXP != 27)  // (timing build 27: the products as plain loops, right results: 98 us per layer against 89)
-#endif
 #define BF3_PRODUCT(NKS, WA, WB, BVAL)                                                                              \
   {                                                                                                                 \
     typedef __attribute__((address_space(3))) u32x4 lds_u4_;                                                        \
@@ -104,12 +101,8 @@ __device__ __forceinline__ void bf3_mfma6(f32x16 &acc, unsigned wa, const u32x4 
       }                                                                                                             \
     }                                                                                                               \
   }
-#if MVN_EXP == 25
-#define BF3_MF1(c_, a_, b_) c_[0] += __uint_as_float(a_[0] ^ b_[0])
-#else
 #define BF3_MF1(c_, a_, b_) \
   c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
-#endif
 
 constexpr int FS3_W1_BYTES = 4 * 8 * 3 * 1024, FS3_W2_BYTES = 4 * 4 * 3 * 1024;  // 96 KB + 48 KB
 constexpr int FS3_LDS_BYTES = FS3_W1_BYTES + FS3_W2_BYTES + 128 * 4;
@@ -171,11 +164,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5;
-#if MVN_EXP == 26  // timing build: the weight staging only, no strip
-  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.d < 0 ? tb + chunk_t : tb;
-#else
   const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
-#endif
   const int skip_lo = max(a.t_begin, a.t_skip0);
   // ---- weights into LDS: the image fs3_pack_kernel wrote once per forward call (a linear 144 KB copy, every load
   // in flight before the first store), or, without one, converted here (17 us per launch: 48 dependent
@@ -213,21 +202,9 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
   const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
   // timing builds (wrong results; python -m movenet_amd.csrc.build --stamps --exp=N, scripts/exp_fwd.sh): 21 no tanh /
   // sigmoid stores, 22 no stores, 23 no loads after a wave's first strip, 24 = 22 + 23, 25 no MFMAs (nor splits)
-#if MVN_EXP == 21 || MVN_EXP == 22 || MVN_EXP == 24
-  const bool aux_ok = a.d < 0;  // (never: the stores stay in the code, none is executed)
-#else
   constexpr bool aux_ok = true;
-#endif
-#if MVN_EXP == 22 || MVN_EXP == 24
-  const bool st_ok = a.d < 0;
-#else
   constexpr bool st_ok = true;
-#endif
-#if MVN_EXP == 23 || MVN_EXP == 24
-  const bool ld_ok = a.d < 0;
-#else
   constexpr bool ld_ok = true;
-#endif
   const bool save = aux_ok && a.th.p != nullptr, has_out = st_ok && a.xout.p != nullptr;
   int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld;
 
@@ -293,18 +270,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#if MVN_BF3_PIPELINED
     BF3_PRODUCT(8, w1a, w1b, (ks_ < 4 ? xb1[8 * ks_ + e_] : xa0[8 * (ks_ - 4) + e_]));
-#else
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      u32x4 bh, bm, bl;
-      bf3_split8(ks < 4 ? &xb1[8 * ks] : &xa0[8 * (ks - 4)], bh, bm, bl);
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-        bf3_mfma6(acc[blk], (blk < 2 ? w1a : w1b) + 3072u * (unsigned)((blk & 1) * 8 + ks), bh, bm, bl);
-    }
-#endif
     // ---- gate in registers; tanh / sigmoid leave; z in accumulator order = the next B operand
     float z[32];
     FS_FENCE(thld4);
@@ -352,18 +318,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_bf3_kernel(FusedFwdPArg
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#if MVN_BF3_PIPELINED
     BF3_PRODUCT(4, w2a, w2b, z[8 * ks_ + e_]);
-#else
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 bh, bm, bl;
-      bf3_split8(&z[8 * ks], bh, bm, bl);
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-        bf3_mfma6(acc[blk], (blk < 2 ? w2a : w2b) + 3072u * (unsigned)((blk & 1) * 4 + ks), bh, bm, bl);
-    }
-#endif
     // ---- x' = (y + br) + x(t): x(t) of this lane's channel is input register 16 h + r;
     // skip (+)= y + bs, columns t - t_base, live from skip_lo
     FS_FENCE(xold4);
@@ -466,11 +421,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
   const int li = lane & 31, lh = lane >> 5;
-#if MVN_EXP == 26  // timing build: the weight staging only, no strip
-  const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = a.d < 0 ? tb + chunk_t : tb;
-#else
   const int tb = (a.t_begin & ~TILE_ALIGN) + ch * chunk_t, te = min(a.t_end, tb + chunk_t);
-#endif
   const int skip_lo = max(a.t_begin, a.t_skip0);
   // ---- weights into LDS: the image fsc_pack_kernel wrote once per forward call (W1 as fp32 MFMA operands,
   // [block][k-step / 4][lane][k-step % 4]; W2 as three bf16 planes; the four bias vectors)
@@ -516,11 +467,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
   const __amdgpu_buffer_rsrc_t xob = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xout.p + (size_t)b * a.xout.sb), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t skb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.skip.p + (size_t)b * a.skip.sb - a.t_base), 0, 0x7FFFFFFF, RSRC);
   const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ctx.p + (size_t)b * a.ctx.sb), 0, 0x7FFFFFFF, RSRC);
-#if MVN_EXP == 13 || MVN_EXP == 14
-  const bool st_ok = a.d < 0;  // (never: the stores stay in the code, none is executed)
-#else
   constexpr bool st_ok = true;
-#endif
   const bool save = st_ok && a.th.p != nullptr, has_out = st_ok && a.xout.p != nullptr;
   int xld4 = 4 * a.xin.ld, thld4 = 4 * a.th.ld, xold4 = 4 * a.xout.ld, skld4 = 4 * a.skip.ld, cld4 = 4 * a.ctx.ld;
   // (row offsets = row * ld are re-formed where they are used, behind a fence on ld: hoisted out of
@@ -587,12 +534,6 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
     // ---- x(t - d) of channel kc(j) + 4 lh: B operand of k-steps 0..31; later the skip accumulator's old values
     float xa0[32];
     FS_FENCE(xld4);
-#if MVN_EXP == 11 || MVN_EXP == 12 || MVN_EXP == 14
-    if (t0 != tb + 32 * wave) {
-#pragma unroll
-      for (int j = 0; j < 32; ++j) xa0[j] = xb1[j] * 0.5f;
-    } else
-#endif
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xb, ox0, ((j & 3) + 8 * (j >> 2)) * xld4, 0));
@@ -649,11 +590,7 @@ __global__ __launch_bounds__(512, 1) void fused_layer64s_ctxw2_kernel(FusedFwdPA
     // the skip accumulator's old values, into the x(t - d) registers (dead now), and the NEXT strip's
     // x(t), both under the MFMAs below
     FS_FENCE(skld4);
-#if MVN_EXP == 12 || MVN_EXP == 14
-    if (false) {
-#else
     if (!a.first_layer) {
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -903,15 +840,9 @@ constexpr size_t DS3_BWD_IMG_F = 4 * DS3_IMG2_F + DS3_IMG2_F;  // backward: conv
 
 // MOVENET_HIP_FORWARD_MFMA=f32 keeps the fp32-MFMA strip kernel (A/B, tests); read per call
 // MOVENET_HIP_HEAD_MFMA=f32 keeps the head's fp32 kernels (strips for the convolutions, the staged kernel for their
-// data gradients); read per call
-static bool head_bf3_enabled() {
-  const char *e = getenv("MOVENET_HIP_HEAD_MFMA");
-  return !(e && e[0] == 'f');
-}
-static bool forward_bf3_enabled() {
-  const char *e = getenv("MOVENET_HIP_FORWARD_MFMA");
-  return !(e && e[0] == 'f');
-}
+// data gradients); common.h: Switches
+static bool head_bf3_enabled() { return !switches().head_f32; }
+static bool forward_bf3_enabled() { return !switches().forward_f32; }
 
 // the LDS images of layers 0 .. L-1 into `dst` (L x FS3_PACK_F floats), one launch per 32 layers
 static int launch_fs3_pack(const mvn_params *p, int L, float *dst, hipStream_t s) {

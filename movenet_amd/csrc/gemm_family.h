@@ -823,9 +823,8 @@ static void launch_wgrad2(const Op &op, int m_rows, int n_rows, int batch, float
   const size_t need = (size_t)chunks * batch * mpad * npad;
   float *part = (slab_scratch && need <= slab_floats) ? slab_scratch : nullptr;
   dim3 grid(chunks * batch, mb * nb);
-  // MOVENET_HIP_WGRAD_MFMA=f32 keeps the fp32-MFMA form (A/B, tests); read per call
-  const char *e = getenv("MOVENET_HIP_WGRAD_MFMA");
-  if (e && e[0] == 'f')
+  // MOVENET_HIP_WGRAD_MFMA=f32 keeps the fp32-MFMA form (A/B, tests; common.h: Switches)
+  if (switches().wgrad_f32)
     hipLaunchKernelGGL((wgrad2_kernel<Op, NB, false>), grid, dim3(256), 0, s, op, nb, chunks, bias_scratch,
                        mpad, part, npad);
   else

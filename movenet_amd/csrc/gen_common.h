@@ -32,11 +32,7 @@ __device__ __forceinline__ int ring_offset(int l, int layer_size, int C) {
 // flight across it.  __syncthreads() would add a full vmcnt(0) drain whenever a
 // global store is pending.
 __device__ __forceinline__ void lds_barrier() {
-#if defined(MVN_EXP) && MVN_EXP == 2
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // timing experiment only (racy)
-#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 __device__ __forceinline__ float ring_load(const float *p) {

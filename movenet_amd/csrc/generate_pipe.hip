@@ -322,11 +322,7 @@ __global__ __launch_bounds__(512, 2) void gen_pipe_kernel(GenArgs a, u64 *hand, 
             dot2_lds<NF4>(wa[j], wb[j], cur + KPER * kq, f, g);
             f = chan_sum<KQ>(f) + pf[j];
             g = chan_sum<KQ>(g) + pg[j];
-#if MVN_EXP == 1
-            const float z = f + g;
-#else
             const float z = gate_fast(f, g);
-#endif
             if (lead) zb[c] = z;
             if (j == 0) MVN_FINE(b, s, ts - a.t_begin, 1, 0);
           } else if (lead) {

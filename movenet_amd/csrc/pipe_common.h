@@ -298,9 +298,6 @@ __device__ __forceinline__ int dpp_movi(int v) {
 
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef MVN_EXP
-#define MVN_EXP 0   // timing experiments of scripts/pipe_stamps.py; 0 = the product
-#endif
 
 // N4*4-term dot product as packed FMAs (v_pk_fma_f32) in two (N4 = 4) or four independent
 // chains, combined in a fixed order.  w: 2*N4 float2, x: the inputs already fetched from LDS.
@@ -485,7 +482,7 @@ __device__ __forceinline__ bool greedy_pick_clear(const float (&lg)[4], int lane
 // `uniform`: philox_uniform(seed, u, b), formed by the caller BEFORE it waits for the step's input (ten
 // Philox rounds of integer multiplies: ~0.15 us that do not depend on the logits).
 __device__ __forceinline__ int choose_class(const float (&lg)[4], float temperature, float uniform, int lane, int Q) {
-  if (MVN_EXP != 71 && !(temperature > 0.f)) {
+  if (!(temperature > 0.f)) {
     int fast;
     if (greedy_pick_clear(lg, lane, fast)) return fast;
   }

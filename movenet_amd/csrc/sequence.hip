@@ -1122,18 +1122,12 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     };
     // C = K = 64, audio only, fp32: the layer as ONE kernel (fused_layer.h); same bits as the
     // two-kernel form below (MOVENET_HIP_NO_FUSED_FORWARD=1 keeps the latter: A/B and tests)
-    const bool no_fused = [] {
-      const char *e = getenv("MOVENET_HIP_NO_FUSED_FORWARD");
-      return e && e[0] == '1';
-    }();
+    const bool no_fused = switches().no_fused_forward;
     // (the layer's weights are re-packed k-major into the z scratch, which this path never
     // touches otherwise: z stays in LDS)
     // ... and its persistent successor (fused_fwd.h: weights in registers, 64-column tiles);
-    // MOVENET_HIP_NO_PERSISTENT_FORWARD=1 keeps the per-tile kernel (read per call: tests run both)
-    const bool no_persistent = [] {
-      const char *e = getenv("MOVENET_HIP_NO_PERSISTENT_FORWARD");
-      return e && e[0] == '1';
-    }();
+    // MOVENET_HIP_NO_PERSISTENT_FORWARD=1 keeps the per-tile kernel (common.h: Switches)
+    const bool no_persistent = switches().no_persistent_forward;
     if (C == FL_C && Kc == FL_C && !f16 && !no_fused && !no_persistent &&
         (!has_ctx || (g.Tp <= (1 << 22) && buf->ctx_ld <= (1 << 22)))) {
       FusedFwdPArgs fp;
@@ -1151,7 +1145,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       fp.sg = act_view(save ? buf->sg + (size_t)l * g.act : nullptr, batch, C, g.Tp);
       // audio-only layers: the strip kernel on the bf16 matrix cores (fp32 = 3 bf16 planes, fused_fwd_bf3.h)
       // unless a tile form / the fp32-MFMA strip was asked for, or the rows are longer than a buffer resource spans
-      const bool bf3 = !fp.ctx.p && forward_bf3_enabled() && !getenv("MOVENET_HIP_FORWARD_TILE") &&
+      const bool bf3 = !fp.ctx.p && forward_bf3_enabled() && !switches().forward_tile &&
                        fp.xin.ld <= (1 << 22) && fp.skip.ld <= (1 << 22);
       if (bf3 && (size_t)g.act >= (size_t)g.L * FS3_PACK_F) {
         // the layers' weights as LDS images (three bf16 planes, the kernel's layout), written once per call into
@@ -1164,7 +1158,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
       }
       // conditioned layers: the strip kernel with its residual | skip product on the bf16 matrix cores and a packed
       // weight image (same switches; the image needs the z scratch)
-      const bool ctxw2 = fp.ctx.p && forward_bf3_enabled() && !getenv("MOVENET_HIP_FORWARD_TILE") &&
+      const bool ctxw2 = fp.ctx.p && forward_bf3_enabled() && !switches().forward_tile &&
                          (size_t)g.act >= (size_t)g.L * FSC_PACK_F;
       if (ctxw2) {
         if (l == 0) {
@@ -1219,10 +1213,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     h1.ldw = Kc; h1.bias = p->head1_b; h1.xin = skipv; h1.yout = a1v; h1.ref = a1v;
     h1.t_out_end = g.pad + g.S; h1.aligned_out = 1;
     // Q = 256, K = 64: the strip form reads the skip sum once (fused_fwd.h); MOVENET_HIP_NO_DENSE_STRIP=1: A/B
-    const bool strip_ok = Kc == 64 && !f16 && [] {
-      const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
-      return !(e && e[0] == '1');
-    }();
+    const bool strip_ok = Kc == 64 && !f16 && !switches().no_dense_strip;
     const bool strip = strip_ok && Q == 256;  // (the fp32 strips: Q = 256 only)
     // r3: both head convolutions as strip kernels on the bf16 matrix cores (fused_fwd_bf3.h), their LDS images
     // packed once per call behind the layers' in the z scratch
@@ -1252,10 +1243,7 @@ static int forward_impl(const mvn_dims *dims, const mvn_params *p, const int32_t
     // `out` is the caller's contiguous (B, Q, S_out): column s of the head = out column s - pad
     h2.yout = act_view(out - g.pad, batch, Q, S_out);
     h2.t_out_end = g.pad + S_out; h2.aligned_out = 0;
-    const bool strip2 = Q == 256 && !f16 && [] {
-      const char *e = getenv("MOVENET_HIP_NO_DENSE_STRIP");
-      return !(e && e[0] == '1');
-    }();
+    const bool strip2 = Q == 256 && !f16 && !switches().no_dense_strip;
     if (head_img && S_out > 0) {
       // four row blocks of 64 on the bf16 matrix cores (fused_fwd_bf3.h)
       DenseStripArgs da;
@@ -1347,15 +1335,11 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     // conditioned pass wrote their bias partials past the end of da1, into whatever tensor came next.
     const size_t wg2 = (size_t)((T + TILE_ALIGN + W2_CHUNK - 1) / W2_CHUNK) * batch;
     const size_t wgf = (size_t)2 * fb_device_cus() + batch;
-#if MVN_EXP == 60  // (test build: the sizing before the fix -- MOVENET_DEBUG_GUARD=1 must catch it)
-    const size_t need = wg2 * ((C + Kc + 127) / 128 * 128);
-#else
     const size_t need = std::max(wg2, wgf) * ((C + Kc + 127) / 128 * 128);
-#endif
     if (need <= slab_floats / 2) {
       slab_floats -= need;
       bias_scratch2 = bwd->da1 + slab_floats;
-      bias2_floats = MVN_EXP == 60 ? (size_t)-1 : need;
+      bias2_floats = need;
     }
   }
   // head weight gradients (wgrad2): slabs + bias partials in dfg
@@ -1480,16 +1464,9 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   SideStream *side = nullptr;
   // MOVENET_HIP_NO_SIDE_STREAM=1 keeps everything on the caller's stream (profiling: kernel
   // durations are only comparable when the kernels do not share the machine)
-  static const bool no_side = [] {
-    const char *e = getenv("MOVENET_HIP_NO_SIDE_STREAM");
-    return e && e[0] == '1';
-  }();
+  const bool no_side = switches().no_side_stream;
   // MOVENET_HIP_NO_FUSED_BACKWARD=1: the two-kernel forms (cross-checks, profiling)
-  // (read per call: tests/test_forward_gpu.py runs both forms in one process)
-  const bool fused_bwd = [] {
-    const char *e = getenv("MOVENET_HIP_NO_FUSED_BACKWARD");
-    return !(e && e[0] == '1');
-  }();
+    const bool fused_bwd = !switches().no_fused_backward;
   // (with both fused halves every kernel of the layer loop runs on the caller's stream: no fork,
   // and none of the two event records + waits per layer that go with it -- ~60 gaps of ~8 us per step)
   const bool all_fused = fused_bwd && C == 64 && Kc == 64;  // (conditioned layers too: bwd_dctx_wgctx64_kernel)
@@ -1511,7 +1488,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
   // Two pairs (A', P0) of (B, C, Tp) tensors alternate between the layers: dx_a | dx_b and -- audio only -- the two
   // row halves of the dfg tensor, which nothing else uses then; conditioned layers still write dfg for the context
   // pass, their second pair lives in dlogit (dead behind the head's backward) when it is large enough.
-  // MOVENET_HIP_BWD_FORM=split keeps the two-half form of r2 / r3 (cross-checks, A/B); read per call.
+  // MOVENET_HIP_BWD_FORM=split keeps the two-half form of r2 / r3 (cross-checks, A/B; common.h: Switches).
   Act spair[2][2];
   bool scatter = false;
   // (tensors too small for the reservation above -- the parity tests' smallest -- get a bias region sized for
@@ -1526,10 +1503,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
       sc_bias = bwd->da1 + sc_slab_floats;
     }
   }
-  if (all_fused && sc_bias && g.L < 4095 && g.Tp <= (1 << 21) && [] {
-        const char *e = getenv("MOVENET_HIP_BWD_FORM");
-        return !(e && e[0] == 's');
-      }()) {
+  if (all_fused && sc_bias && g.L < 4095 && g.Tp <= (1 << 21) && !switches().bwd_split) {
     spair[0][0] = act_view(bwd->dx_a, batch, C, g.Tp);
     spair[0][1] = act_view(bwd->dx_b, batch, C, g.Tp);
     bool have = true;
@@ -1730,10 +1704,7 @@ int mvn_backward(const mvn_dims *dims, const mvn_params *p, const mvn_param_grad
     if (C == 64 && Q % EG64_PARTS == 0 && (size_t)Q / EG64_PARTS * 64 * sizeof(float) <= 64 * 1024 && slab &&
         (size_t)chunks64 * batch * 2 * Q * 64 <= slab_floats) {
       // MOVENET_HIP_EMBED_GRAD=scalar keeps the LDS read-modify-write kernel (A/B, tests); Q = 256: the product form
-      const bool mfma_form = Q == 256 && [] {
-        const char *e = getenv("MOVENET_HIP_EMBED_GRAD");
-        return !(e && e[0] == 's');
-      }();
+      const bool mfma_form = Q == 256 && !switches().embed_scalar;
       if (mfma_form) {
         hipLaunchKernelGGL(embed_grad64_mfma_kernel, dim3(chunks64, batch), dim3(256), 0, s, index, index_stride,
                            act_view(dxo_p, batch, C, g.Tp), T, slab);

@@ -80,6 +80,8 @@ class ForwardBuffers:
         f32 = dict(dtype=torch.float32, device=device)
         # (MOVENET_DEBUG_GUARD=1: a band of sentinels behind every buffer, checked after mvn_forward)
         self.guard = _GuardBands(device) if os.environ.get("MOVENET_DEBUG_GUARD") == "1" else None
+        if self.guard is not None:
+            lib.mvn_reload_switches()  # (debug / test mode: the MOVENET_HIP_* A/B switches may change inside the process)
         alloc = torch.empty if self.guard is None else self.guard.empty
         self.acts = alloc(((L + 1) if save else 2, batch, C, self.Tp), **f32)
         self.th = alloc((L, batch, C, self.Tp), **f32) if save else None
@@ -225,6 +227,8 @@ def _run_backward(ctx_, params, out, dout, fill_dlogit):
         # MOVENET_DEBUG_GUARD=1 (tests): every scratch tensor of the backward pass gets a guard band behind it,
         # checked after the call -- the library carves its slab / partial-sum scratch out of these tensors
         guard = _GuardBands(dev) if os.environ.get("MOVENET_DEBUG_GUARD") == "1" else None
+        if guard is not None:
+            lib.mvn_reload_switches()
         alloc = torch.empty if guard is None else guard.empty
         dx_a = alloc((B, C, buf.Tp), **f32)
         dx_b = alloc((B, C, buf.Tp), **f32)
