@@ -38,8 +38,16 @@
 // replaces); two wave roles (waves 0-3 the data path over full K with 96 plane registers of tap weights and no K halves
 // to meet, waves 4-7 both weight gradients as 2 x 2 blocks: 52 splits per SIMD and tile instead of 64, four barriers
 // instead of five) -- 209 against 198 us: the prefetched tile no longer fits the register file and waits in scratch.
-// What would lift it is operands split ONCE into planes in LDS (88 wave-splits per tile instead of 256), which needs
-// 1.5 x the LDS per tile: 179 KB at this tile width.
+// Operands split ONCE into planes in LDS was built too (r4b, a whole second kernel, parity green on its first run): tiles as
+// [row][64 t] bf16 x three planes written by the staging threads and by the gate, row operands fetched with one ds_read_b128
+// per plane, operands read across the tile's rows with two ds_read_b64_tr_b16 per plane (the CDNA4 transposed read;
+// scripts/probes/tr_read.hip pins its lane map: element j of lane (li, lh) = tile[r0 + 8 lh + j][c0 + li]), 700 vector
+// instructions per wave and tile instead of 1900.  The planes are 1.5 x the bytes, so the dz weights leave LDS for
+// registers, and 96 plane registers of resident weights do not fit beside the accumulators: the compiler keeps part of them
+// in scratch and reloads them in front of the MFMAs that need them (225 us per layer); streamed from packed images per tile
+// instead (dz weights: 204 us; tap weights too: 234 us -- the tile's own loads queue behind 144 KB of weight loads per tile
+// and CU).  Same box, the form above: 187-195 us.  With 256 registers per wave at two waves per SIMD and 160 KB of LDS the
+// two forms meet at the same place from opposite sides; the next step would be four waves of 512 registers per CU.
 #pragma once
 #include "fused_bwd.h"
 #include "fused_fwd.h"
@@ -549,10 +557,11 @@ static int launch_bwd_layer64(const FusedBwdLArgs &a, const RsOp &rs, const FgOp
   }
   const int n = pl.chunks * batch;
   const void *fn = wd ? (const void *)bwd_layer64_kernel<true> : (const void *)bwd_layer64_kernel<false>;
+  constexpr size_t lds_bytes = FBL_LDS_BYTES;
   const int rc = ensure_max_dynamic_lds(fn, "hipFuncSetAttribute(bwd_layer64)");
   if (rc) return rc;
   void *args[] = {(void *)&a, (void *)&pl.chunks, (void *)&pl.chunk_t, (void *)&pl.bias, (void *)&pl.rs, (void *)&pl.fg};
-  if (check_hip(hipLaunchKernel(fn, dim3(n), dim3(512), args, FBL_LDS_BYTES, s), "bwd_layer64")) return MVN_ERR_LAUNCH;
+  if (check_hip(hipLaunchKernel(fn, dim3(n), dim3(512), args, lds_bytes, s), "bwd_layer64")) return MVN_ERR_LAUNCH;
   hipLaunchKernelGGL((reduce_layer64_kernel<RsOp, FgOp>), dim3(260 + 128 * 128 / 32), dim3(32 * RED_SEG), 0, s, rs, pl.rs,
                      pl.bias, n, fg, pl.fg, n);
   return MVN_OK;
