@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MVN_ABI_VERSION 1
+#define MVN_ABI_VERSION 2  /* r4: mvn_upsample_video_backward takes a scratch buffer; new entry points */
 
 #define MVN_OK 0
 #define MVN_ERR_BAD_DIMS (-1)      /* unsupported / inconsistent dimensions   */
@@ -329,12 +329,16 @@ int mvn_upsample_video(const mvn_dims *dims, const mvn_video_params *vp, const f
                        int batch, int frames, int cin, float *enc, float *u1, float *u2, float *ctx,
                        int ctx_ld, void *stream);
 
-/* d_u2, d_u1, d_enc: scratch of the same shapes as u2, u1, enc. */
+/* d_u2, d_u1, d_enc: scratch of the same shapes as u2, u1, enc.  `scratch` (r4): room for the per-workgroup
+ * weight-gradient slabs of the up-sampler's backward kernel (C = 64), mvn_upsample_video_scratch_floats(dims, batch,
+ * frames) floats; NULL or too small: the gradients are added with atomics instead (correct, ~5x slower, and the
+ * summation order then varies from run to run). */
+size_t mvn_upsample_video_scratch_floats(const mvn_dims *dims, int batch, int frames);
 int mvn_upsample_video_backward(const mvn_dims *dims, const mvn_video_params *vp,
                                 const mvn_video_grads *vg, const float *video, int batch, int frames,
                                 int cin, const float *enc, const float *u1, const float *u2,
                                 const float *dctx, int dctx_ld, float *d_u2, float *d_u1,
-                                float *d_enc, void *stream);
+                                float *d_enc, float *scratch, size_t scratch_floats, void *stream);
 
 /* Fill the generator's dilation queues from a saved forward (acts of a prompt
  * of t_len >= RF samples): equivalent to mvn_generate over t in [0, t_len-1). */

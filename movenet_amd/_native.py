@@ -125,11 +125,12 @@ SIGNATURES = {
     "mvn_upsample_video": (C.c_int, [C.POINTER(Dims), C.POINTER(VideoParams), C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p]),
+    "mvn_upsample_video_scratch_floats": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int]),
     "mvn_upsample_video_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(VideoParams),
                                               C.POINTER(VideoParams), C.c_void_p, C.c_int, C.c_int,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_void_p]),
+                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mvn_gen_prime_from_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(FwdBuffers), C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "mvn_ce_parts": (C.c_int, [C.c_int, C.c_int]),
@@ -178,7 +179,7 @@ def lib() -> C.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if handle.mvn_abi_version() != 1:
+    if handle.mvn_abi_version() != 2:
         raise NativeLibraryError("libmovenet_hip.so ABI version mismatch")
     _lib = handle
     return handle

@@ -376,10 +376,12 @@ class _UpsampleVideoFunction(torch.autograd.Function):
                                (C_void3)(grads[2].data_ptr(), grads[4].data_ptr(), grads[6].data_ptr()),
                                (C_void3)(grads[3].data_ptr(), grads[5].data_ptr(), grads[7].data_ptr()))
             d_u2, d_u1, d_enc = torch.empty_like(u2), torch.empty_like(u1), torch.empty_like(enc)
+            n_scratch = int(lib.mvn_upsample_video_scratch_floats(dims, B, F))  # per-workgroup weight-gradient slabs
+            scratch = torch.empty(max(n_scratch, 1), dtype=torch.float32, device=dev)
             N.check(lib.mvn_upsample_video_backward(
                 dims, vp, vg, video.data_ptr(), B, F, cin, enc.data_ptr(), u1.data_ptr(),
                 u2.data_ptr(), dout.data_ptr(), dout.stride(1), d_u2.data_ptr(), d_u1.data_ptr(),
-                d_enc.data_ptr(), _stream_ptr(dev)), "mvn_upsample_video_backward")
+                d_enc.data_ptr(), scratch.data_ptr(), n_scratch, _stream_ptr(dev)), "mvn_upsample_video_backward")
         need = ctx_.needs_input_grad[3:]
         return (None, None, None, *[g if w else None for g, w in zip(grads, need)])
 

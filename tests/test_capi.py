@@ -23,7 +23,7 @@ def test_header_symbols_all_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in movenet_hip.h but not exported"
     assert sorted(N.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.mvn_abi_version() == 1
+    assert lib.mvn_abi_version() == 2
 
 
 def test_receptive_fields_and_output_size():
