@@ -65,4 +65,68 @@ __device__ __forceinline__ void bf3_mfma6r(f32x16 &acc, const u32x4 &ah, const u
 #undef BF3_MFR
 }
 
+// A third of a split, in place: the top-16 plane of eight values, the values replaced by their residuals (20 vector
+// instructions); applied twice it yields h and m, bf3_pack_l then packs what is left (4)
+__device__ __forceinline__ void bf3_peel(float *x, u32x4 &p) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned at = bf3_top(x[2 * i]), bt = bf3_top(x[2 * i + 1]);
+    p[i] = __builtin_amdgcn_perm(bt, at, 0x07060302);
+    x[2 * i] -= __uint_as_float(at);
+    x[2 * i + 1] -= __uint_as_float(bt);
+  }
+}
+__device__ __forceinline__ void bf3_pack_l(const float *r, u32x4 &l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) l[i] = __builtin_amdgcn_perm(__float_as_uint(r[2 * i + 1]), __float_as_uint(r[2 * i]), 0x07060302);
+}
+
+// One slot of a software-pipelined bf16 x 3 product (fused_bwd_l.h, phase 2): the six MFMAs of an operand whose h plane is
+// ready (f1..f3 need h only, f4, f5 the m plane, f6 the l plane), with the 44 vector instructions that form the m and l
+// planes of THIS operand (residuals in xc, in place) and the h plane of the NEXT one (values in xn, replaced by their
+// residuals) cut into six pieces behind the MFMAs: 7 + 7 + 6 (m), 8 (l, first of the next h), 8, 8.  A wave issues in
+// order and an MFMA holds the SIMD's vector port for 8 of its 32 cycles only: split-then-multiply leaves the matrix pipe idle
+// for the split and the vector port idle for the MFMAs, and the SIMD's other wave fills only part of either (scripts/probes/
+// simd_pairing.hip).  Scheduling barriers keep the pieces where they are (scheduling GROUPS filled them unevenly: 7 / 1 / 12,
+// then two MFMAs back to back).  Terms are summed h-terms first, then m, then l -- a different rounding order than
+// bf3_mfma6r's smallest-first, same six terms.
+template <class F1, class F2, class F3, class F4, class F5, class F6>
+__device__ __forceinline__ void bf3_slot(const bool has_next, float *xc, float *xn, u32x4 &mc, u32x4 &lc, u32x4 &hn, F1 f1, F2 f2, F3 f3,
+                                         F4 f4, F5 f5, F6 f6) {
+#define BF3_SB __builtin_amdgcn_sched_barrier(0)
+  unsigned t0, t1, t2, t3;
+  f1(); BF3_SB;
+  t0 = bf3_top(xc[0]); t1 = bf3_top(xc[1]); mc[0] = __builtin_amdgcn_perm(t1, t0, 0x07060302);
+  xc[0] -= __uint_as_float(t0); xc[1] -= __uint_as_float(t1);
+  t2 = bf3_top(xc[2]); t3 = bf3_top(xc[3]);
+  BF3_SB; f2(); BF3_SB;
+  mc[1] = __builtin_amdgcn_perm(t3, t2, 0x07060302); xc[2] -= __uint_as_float(t2); xc[3] -= __uint_as_float(t3);
+  t0 = bf3_top(xc[4]); t1 = bf3_top(xc[5]); mc[2] = __builtin_amdgcn_perm(t1, t0, 0x07060302); xc[4] -= __uint_as_float(t0);
+  BF3_SB; f3(); BF3_SB;
+  xc[5] -= __uint_as_float(t1);
+  t2 = bf3_top(xc[6]); t3 = bf3_top(xc[7]); mc[3] = __builtin_amdgcn_perm(t3, t2, 0x07060302);
+  xc[6] -= __uint_as_float(t2); xc[7] -= __uint_as_float(t3);
+  BF3_SB; f4(); BF3_SB;
+  bf3_pack_l(xc, lc);
+  if (has_next) {
+    t0 = bf3_top(xn[0]); t1 = bf3_top(xn[1]); hn[0] = __builtin_amdgcn_perm(t1, t0, 0x07060302);
+    xn[0] -= __uint_as_float(t0);
+  }
+  BF3_SB; f5(); BF3_SB;
+  if (has_next) {
+    xn[1] -= __uint_as_float(t1);
+    t2 = bf3_top(xn[2]); t3 = bf3_top(xn[3]); hn[1] = __builtin_amdgcn_perm(t3, t2, 0x07060302);
+    xn[2] -= __uint_as_float(t2); xn[3] -= __uint_as_float(t3);
+    t0 = bf3_top(xn[4]); t1 = bf3_top(xn[5]);
+  }
+  BF3_SB; f6(); BF3_SB;
+  if (has_next) {
+    hn[2] = __builtin_amdgcn_perm(t1, t0, 0x07060302); xn[4] -= __uint_as_float(t0); xn[5] -= __uint_as_float(t1);
+    t2 = bf3_top(xn[6]); t3 = bf3_top(xn[7]); hn[3] = __builtin_amdgcn_perm(t3, t2, 0x07060302);
+    xn[6] -= __uint_as_float(t2); xn[7] -= __uint_as_float(t3);
+  }
+  BF3_SB;
+#undef BF3_SB
+}
+
 }  // namespace mvn

@@ -18,22 +18,35 @@
 // pitch 68, and [Wr | Ws]^T as three bf16 planes (48 KB, the dz product's A operand): 150 KB.  Every product runs on
 // the bf16 matrix cores in the bf16 x 3 form (bf3.h), each phase as an OPERAND PIPELINE -- the LDS reads of stage s + 1
 // are issued ahead of the split and the six MFMAs of stage s:
-//   phase 1 (12 stages per wave): wave (K half, t block, c block) forms its half of a 32 c x 32 t block of dz (K = 64
+//   phase 1 (12 slots per wave): wave (K half, t block, c block) forms its half of a 32 c x 32 t block of dz (K = 64
 //            of the tile's 128 rows, read across rows; weights from LDS) and ONE block of the residual / skip weight
 //            gradient (K = time); the tile's x rows are in flight meanwhile and land in U behind the barrier;
 //   gate:    the two K halves of a block meet through the idle P0 staging rows, each wave handing over the half of its
 //            partial sums the other one finishes: all eight waves turn tanh | sigmoid into df | dg in place;
-//   phase 2 (20 stages): as bwd_dx_wgfg64_kernel -- wave (tap, K half, channel block) forms both 32-step blocks of its
-//            tap's product with its 48 plane registers of W_tap, every wave owns two blocks of the filter / gate weight
-//            gradient; the next tile's loads are issued in parts between the stages; the K halves meet in O.
+//   phase 2 (20 slots): wave (tap, K half, channel block) forms both 32-step blocks of its tap's product with its 48 plane
+//            registers of W_tap, every wave owns two blocks of the filter / gate weight gradient; the next tile's loads
+//            are issued in parts between the slots; the K halves meet in O.
+// Both phases are software-pipelined INSIDE the wave (r4c, bf3_slot in bf3.h): a slot issues the LDS reads of the next
+// operand, then the six MFMAs of this one with, behind them, this operand's m and l planes and the next operand's h plane.
 // Five barriers per tile (the two halves had three each).  Slabs and bias partial sums leave in wgrad2's format;
 // reduce_layer64_kernel adds them up.
 //
 // Where its time goes (timing builds 71-74 and the stamps of build 76, config 2, same box, us per layer): 198-209 as built,
-// 190 without any global access, 130 without MFMAs -- an ON-CHIP time, and by the stamps a vector-issue time: a tile
-// costs 23.6 k cycles, 16.8 k of them in the two phases, where every stage is a split of eight values (44 vector
-// instructions) feeding six MFMAs and two waves share a SIMD's vector port (54.9 M vector instructions per launch =
-// 1900 per wave and tile, matrix pipe busy 36 %).  Measured on the way, none kept: the split's residuals as packed
+// 190 without any global access, 130 without MFMAs -- an ON-CHIP time.  By the stamps a tile costs 23.6 k cycles, 16.8 k of
+// them in the two phases, where every stage is a split of eight values (44 vector instructions) feeding six MFMAs (54.9 M
+// vector instructions per launch = 1900 per wave and tile, matrix pipe busy 36 %).  The two waves of a SIMD do NOT share it
+// evenly: waves 0-3 (the older ones) finish phase 2 in 8.1 k cycles and wait 3.5 k at the barrier, waves 4-7 take 10.9 k
+// (phase 1: 4.8 k / 6.1 k) -- the SIMD issues from the older wave whenever it can, and a straight-line stream of MFMAs and
+// vector instructions always can.  Tried on that (r4c; scripts/probes/simd_pairing.hip, dot2_split.hip;
+// same-box timing builds, none kept): waves 4-7 entering a phase 128 .. 320 cycles late (no change, not even the sleep's
+// cost: the partner fills in); static or per-stage alternating s_setprio (+1 .. +3 %); idle cycles in front of every MFMA so
+// that the partner's MFMAs fit in between (+7 .. +40 %: they do not); the residuals through v_dot2c_f32_bf16 (28
+// instructions per split instead of 44, but the instruction runs at a quarter of the rate).  Kept: the split of operand s + 1
+// and the low planes of operand s BEHIND the MFMAs of operand s (bf3_slot): waves 0-3 phase 2 8.1 k -> 6.6 k cycles, waves
+// 4-7 10.9 k -> 10.5 k, the kernel 1 - 2 % (203.9 -> 202.1 us on one box, 213.9 -> 209.2 on another).  In the probe two
+// waves running [44 vector instructions][6 MFMAs] loops share a SIMD at 222 cycles per stage (pipe bound 192) when every
+// stage ends in a branch, 246 - 250 with four stages between branches, and this kernel's unrolled phases run at 262 - 272.
+// Measured earlier, none kept: the split's residuals as packed
 // subtractions (36 instructions instead of 44: 212.6 against 205.5 us -- a v_pk_add_f32 costs more than the two adds it
 // replaces); two wave roles (waves 0-3 the data path over full K with 96 plane registers of tap weights and no K halves
 // to meet, waves 4-7 both weight gradients as 2 x 2 blocks: 52 splits per SIMD and tile instead of 64, four barriers
@@ -267,8 +280,7 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) accd[r] = 0.f;
     {
-      // ---- phase 1 as an operand pipeline of 12 stages: the LDS reads of stage s + 1 are issued before the split and
-      // the six MFMAs of stage s (left to the scheduler, every split waited out a read issued right in front of it).
+      // ---- phase 1: 12 slots
       //   stages 0-3:  dz (32 c x 32 t), this wave's K half = [Wr | Ws]^T (A: planes in LDS) x [dxo; dskip] (B: read
       //                across the tile's rows), one k-step each;
       //   stages 4-11: residual / skip weight gradient, rows [32 wm, +32) of [dxo; dskip] x z^T (channels [32 wn, +32)),
@@ -292,27 +304,53 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
           }
         }
       };
+      // software-pipelined like phase 2 (bf3_slot): slot s reads operand s + 1 (and the next k-step's weight planes), then
+      // issues the MFMAs of operand s with its m and l planes and the h plane of operand s + 1 formed behind them
+      typedef __attribute__((address_space(3))) u32x4 lds_u4;
+      u32x4 wA[2][3], hc, hn, mc, lc, ah, am, al;
+      auto fetchA = [&](int sI, u32x4 (&w)[3]) {
+        const unsigned wa = wa0 + 3072u * (unsigned)(cb1 * 8 + 4 * kh1 + sI);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[pl] = *(const lds_u4 *)(uintptr_t)(wa + 1024u * pl);
+      };
       fetch1(0, ob[0]);
-      u32x4 ah, am, al;
-#pragma unroll
+      fetchA(0, wA[0]);
+      bf3_peel(ob[0], hc);
+      __builtin_amdgcn_sched_barrier(0);
+#if MVN_EXP == 74
+#define FBL_MF(acc_, a_, b_) acc_[0] += __uint_as_float(a_[0] ^ b_[0])
+#else
+#define FBL_MF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+#endif
+#pragma clang loop unroll(full)
       for (int sI = 0; sI < 12; ++sI) {
-        if (sI + 1 < 12) fetch1(sI + 1, ob[(sI + 1) & 1]);
+        float (&xc)[8] = ob[sI & 1];
+        float (&xn)[8] = ob[(sI + 1) & 1];
+        if (sI + 1 < 12) fetch1(sI + 1, xn);
+        if (sI + 1 < 4) fetchA(sI + 1, wA[(sI + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (sI >= 4 && ((sI - 4) & 1)) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ob[sI & 1][e] *= sgv[e];
-        }
-        u32x4 h, m, l;
-        bf3_split8(ob[sI & 1], h, m, l);
         if (sI < 4) {
-          bf3_mfma6(accd, wa0 + 3072u * (unsigned)(cb1 * 8 + 4 * kh1 + sI), h, m, l);
+          const u32x4 &wh = wA[sI & 1][0], &wmid = wA[sI & 1][1], &wl = wA[sI & 1][2];
+          bf3_slot(true, xc, xn, mc, lc, hn,
+                   [&]() { FBL_MF(accd, wl, hc); }, [&]() { FBL_MF(accd, wmid, hc); }, [&]() { FBL_MF(accd, wh, hc); },
+                   [&]() { FBL_MF(accd, wmid, mc); }, [&]() { FBL_MF(accd, wh, mc); }, [&]() { FBL_MF(accd, wh, lc); });
         } else if (((sI - 4) & 1) == 0) {
-          ah = h; am = m; al = l;
+          // the row operand's planes; then z = tanh x sigmoid of the next slot and its h plane
+          ah = hc;
+          bf3_peel(xc, am);
+          bf3_pack_l(xc, al);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xn[e] *= sgv[e];
+          bf3_peel(xn, hn);
         } else {
-          bf3_mfma6r(accr, ah, am, al, h, m, l);
+          bf3_slot(sI + 1 < 12, xc, xn, mc, lc, hn,
+                   [&]() { FBL_MF(accr, al, hc); }, [&]() { FBL_MF(accr, am, hc); }, [&]() { FBL_MF(accr, ah, hc); },
+                   [&]() { FBL_MF(accr, am, mc); }, [&]() { FBL_MF(accr, ah, mc); }, [&]() { FBL_MF(accr, ah, lc); });
         }
+        hc = hn;
         __builtin_amdgcn_sched_barrier(0);
       }
+#undef FBL_MF
       // the two K halves of a block meet through the P0 staging rows, each wave handing over the HALF of its partial
       // sums the other one finishes (registers 8 (1 - kh1) .. +8), so that all eight waves share the gate derivative
 #pragma unroll
@@ -370,10 +408,12 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) accd2[ub][r] = 0.f;
     {
-      // an operand pipeline of 20 stages, five per 16 time steps: the weight gradient's row operand of dfg, its two x
-      // operands (six MFMAs each), then this wave's k-step of the tap product for both 32-step blocks (operand read
-      // ACROSS the tile's rows; six MFMAs each).  The LDS reads of stage s + 1 are issued ahead of stage s.
-      float ob[2][8];
+      // 20 slots, five per 16 time steps -- the weight gradient's row operand of dfg (planes only), its two x operands, then
+      // this wave's k-step of the tap product for both 32-step blocks (operand read ACROSS the tile's rows) -- software-
+      // pipelined INSIDE the wave (r4c): slot s issues the LDS reads of operand s + 1, then the six MFMAs of operand s with,
+      // behind them, the m and l planes of operand s and the h plane of operand s + 1 (bf3_slot): no vector instruction
+      // stands in front of an MFMA it does not feed.
+      float xb[2][8];
       auto fetch2 = [&](int sI, float (&o)[8]) {
         const int G = sI / 5, k = sI - 5 * G;
         if (k < 3) {
@@ -385,28 +425,46 @@ __global__ __launch_bounds__(512, 1) void bwd_layer64_kernel(FusedBwdLArgs a, in
           for (int e = 0; e < 8; ++e) o[e] = Gt[64 * kh + 16 * G + 8 * lh + e][32 * (k - 3) + li];
         }
       };
-      fetch2(0, ob[0]);
-      u32x4 ah, am, al;
-#pragma unroll
+      u32x4 hc, hn, mc, lc, ah, am, al;
+      fetch2(0, xb[0]);
+      bf3_peel(xb[0], hc);
+      __builtin_amdgcn_sched_barrier(0);
+#if MVN_EXP == 74
+#define FBL_MF(acc_, a_, b_) acc_[0] += __uint_as_float(a_[0] ^ b_[0])
+#else
+#define FBL_MF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+#endif
+#pragma clang loop unroll(full)
       for (int sI = 0; sI < 20; ++sI) {
         const int G = sI / 5, k = sI - 5 * G;
-        if (sI + 1 < 20) fetch2(sI + 1, ob[(sI + 1) & 1]);
+        float (&xc)[8] = xb[sI & 1];
+        if (sI + 1 < 20) fetch2(sI + 1, xb[(sI + 1) & 1]);
         if (spread && k == 0) {
           gload_r_part(t0 + TT, G);
           if (G == 3) gload_r_part(t0 + TT, 4);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        u32x4 h, m, l;
-        bf3_split8(ob[sI & 1], h, m, l);
+        __builtin_amdgcn_sched_barrier(0);  // (the reads stay in front; the planes formed from them wait where they are used)
         if (k == 0) {
-          ah = h; am = m; al = l;
+          ah = hc;
+          bf3_peel(xc, am);
+          bf3_pack_l(xc, al);
+          bf3_peel(xb[(sI + 1) & 1], hn);
         } else if (k < 3) {
-          bf3_mfma6r(accw[k - 1], ah, am, al, h, m, l);
+          f32x16 &acc = accw[k - 1];
+          bf3_slot(sI + 1 < 20, xc, xb[(sI + 1) & 1], mc, lc, hn,
+                   [&]() { FBL_MF(acc, al, hc); }, [&]() { FBL_MF(acc, am, hc); }, [&]() { FBL_MF(acc, ah, hc); },
+                   [&]() { FBL_MF(acc, am, mc); }, [&]() { FBL_MF(acc, ah, mc); }, [&]() { FBL_MF(acc, ah, lc); });
         } else {
-          bf3_mfma6r(accd2[k - 3], h, m, l, wp[G][0], wp[G][1], wp[G][2]);
+          f32x16 &acc = accd2[k - 3];
+          const u32x4 &wh = wp[G][0], &wmid = wp[G][1], &wl = wp[G][2];
+          bf3_slot(sI + 1 < 20, xc, xb[(sI + 1) & 1], mc, lc, hn,
+                   [&]() { FBL_MF(acc, hc, wl); }, [&]() { FBL_MF(acc, hc, wmid); }, [&]() { FBL_MF(acc, hc, wh); },
+                   [&]() { FBL_MF(acc, mc, wmid); }, [&]() { FBL_MF(acc, mc, wh); }, [&]() { FBL_MF(acc, lc, wh); });
         }
+        hc = hn;
         __builtin_amdgcn_sched_barrier(0);
       }
+#undef FBL_MF
     }
     FBL_STAMP(3)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's loads, ahead of this tile's stores
