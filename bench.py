@@ -188,6 +188,37 @@ def cpu_baseline(sd, n_timed: int = 16, n_warm: int = 2):
     }
 
 
+def cpu_train_baseline(sd, batch: int = 2, t_len: int = 16000, n_timed: int = 3, n_warm: int = 1):
+    """the reference's train step -- forward, cross_entropy on the probabilities, backward, AdamW -- through the
+    CPU oracle (torch CPU fp32 autograd on oracle/wavenet_oracle.py) on the host cores, at B = 2 (memory), T = 16000."""
+    from oracle import wavenet_oracle as O
+    from movenet_amd.utils.weights import one_hot, synthetic_indices
+    import torch.nn.functional as F
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    dims = O.Dims(**CFG)
+    rf = dims.receptive_fields
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if not k.startswith("video_") and "context" not in k}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-4)
+    audio = one_hot(synthetic_indices(batch, t_len, CFG["input_channels"], 1234), CFG["input_channels"])
+    target = audio[:, :, rf:].argmax(1)
+    t0 = None
+    for i in range(n_warm + n_timed):
+        if i == n_warm:
+            t0 = time.perf_counter()
+        log(f"cpu_train_baseline: step {i + 1}/{n_warm + n_timed}")
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(O.forward(params, dims, audio), target)
+        loss.backward()
+        opt.step()
+    dt = (time.perf_counter() - t0) / n_timed
+    tokens = batch * (t_len - rf)
+    return {"value": tokens / dt, "unit": "tokens/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"{n_timed} steps after {n_warm} warm-up of the reference's train step (oracle forward, cross_entropy on "
+                      f"probabilities, autograd backward, AdamW) at B={batch}, T={t_len} ({tokens} tokens per step), torch CPU "
+                      f"fp32, {dt:.2f} s per step"}
+
+
 def dilations(cfg):
     return [1 << i for _ in range(cfg["stack_size"]) for i in range(cfg["layer_size"])]
 
@@ -334,8 +365,8 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-    log(f"rank {rank}: config-{config} train steps (ms) "
-        f"{[round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(steps)]}")
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    log(f"rank {rank}: config-{config} train steps (ms) {[round(x, 1) for x in step_ms]}")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -354,6 +385,8 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
     return {"metric": "train-step tokens/sec", "value": tokens_per_step * steps / dt, "unit": "tokens/s",
             "workload": wl["name"], "conditioned": bool(frames),
             "ms_per_step": dt / steps * 1e3, "global_batch": world * batch, "seq_len": t_len,
+            # (value and ms_per_step are the MEAN over every timed step; a host hiccup in one step shows here)
+            "step_ms_rank0": [round(x, 3) for x in step_ms], "ms_per_step_median_rank0": sorted(step_ms)[len(step_ms) // 2],
             "tokens_per_step": tokens_per_step, "optimizer": "AdamW (FlatAdamW, one launch)",
             "dtype": "f32 (tensors, accumulation and results; most products formed exactly from three bf16 planes per operand)",
             "loss": float(loss.detach()), "optimizer_launches_per_step": opt.last_launches,
@@ -831,6 +864,10 @@ def main():
             out["cpu_cached_algorithm"] = cached
             # naive CPU -> cached CPU = the algorithmic change (Q4); cached CPU -> this = hardware
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            if isinstance(out.get("train_step"), dict):
+                tb = cpu_train_baseline(sd_cpu)
+                out["train_step"]["cpu_baseline"] = tb
+                out["train_step"]["speedup_vs_cpu_baseline"] = out["train_step"]["value"] / tb["value"]
             out["speedup_split"] = {"algorithm_cached_over_windowed_cpu": cached["value"] / cb["value"],
                                     "hardware_gpu_over_cached_cpu": value / cached["value"]}
         else:
