@@ -60,7 +60,9 @@
 // in scratch and reloads them in front of the MFMAs that need them (225 us per layer); streamed from packed images per tile
 // instead (dz weights: 204 us; tap weights too: 234 us -- the tile's own loads queue behind 144 KB of weight loads per tile
 // and CU).  Same box, the form above: 187-195 us.  With 256 registers per wave at two waves per SIMD and 160 KB of LDS the
-// two forms meet at the same place from opposite sides; the next step would be four waves of 512 registers per CU.
+// two forms meet at the same place from opposite sides.  (Four waves of 512 registers per CU would NOT be the next step: a
+// wave never overlaps its own vector instructions with its own MFMAs -- scripts/probes/simd_pairing.hip -- only the SIMD's
+// other wave's work hides under an MFMA.)
 #pragma once
 #include "fused_bwd.h"
 #include "fused_fwd.h"

@@ -5,11 +5,15 @@
 // raises the wave's priority for its vector block (s_setprio 1 ... 0), PRIO = 2 for its MFMA block; PRIO 10 .. 16 run the real
 // stage of fused_bwd_l.h (split of eight values, then the six MFMAs it feeds): 10 / 11 one stage per loop iteration (mask as
 // a literal / in an SGPR), 12 two, 13 four stages between branches, 14 - 16 four stages with a taken branch to the next
-// instruction / s_sleep 0 / nops around such a branch between them.  Per "unit" = 44 vector instructions + 6 MFMAs: cycles
+// instruction / s_sleep 0 / nops around such a branch between them, 17 / 18 four stages with s_setprio 1 around every MFMA block /
+// every split.  Per "unit" = 44 vector instructions + 6 MFMAs: cycles
 // of the SIMD.  Measured (MI355X, gpurun_out/simd_pairing.txt): vector-only 236 alone / 118 per unit with two waves; MFMA-only
 // 204 / 197 (the pipe); the stage 400 alone and 222 per unit with two waves when every stage ends in the loop's branch, but 250 /
 // 246 with two / four stages between branches -- then wave 0 runs at 400 - 408 and the younger wave gets what is left --
-// and no yield point tried (14 - 16) brings the even sharing back; priorities change nothing (226 / 222 / 221).
+// and no yield point tried (14 - 16) brings the even sharing back; priorities change nothing (226 / 222 / 221) or hurt (17: 265,
+// 18: 258).  ONE wave never overlaps its own vector instructions with its own MFMAs: [7 v_sub][1 MFMA] loops run at 72 cycles
+// per iteration alone (= 7 x 5.4 + 32 + the branch), the stage at 360 - 400 (= split + 6 x 32): whatever hides under an MFMA is
+// the OTHER wave's work, which is why two waves per SIMD (256 registers each) beat one wave of 512 for this arithmetic.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,11 +52,16 @@ __global__ __launch_bounds__(512) void probe(float *out, const float *src, long 
   for (int it = 0; it < iters; ++it) {
     if (PRIO >= 10) {  // the real stage: split (PRIO 10: literal mask, 11: mask in an SGPR), then six MFMAs fed by it
       u32x4 h, m, l;
+      if (PRIO == 18) __builtin_amdgcn_s_setprio(1);
       if (PRIO == 10) split8<false>(x, h, m, l, mask_r); else split8<true>(x, h, m, l, mask_r);
+      __builtin_amdgcn_sched_barrier(0);
+      if (PRIO == 17) __builtin_amdgcn_s_setprio(1);
+      if (PRIO == 18) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
 #define MFX(a_, b_) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc[0], 0, 0, 0)
       MFX(l, pa); MFX(h, pb); MFX(m, pb); MFX(m, pa); MFX(h, pb); MFX(h, pa);
       __builtin_amdgcn_sched_barrier(0);
+      if (PRIO == 17) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(x[i]));
       if (PRIO >= 12) {  // 12: a second stage per round on the other accumulator; 13: three more (four stages between branches)
@@ -62,11 +71,16 @@ __global__ __launch_bounds__(512) void probe(float *out, const float *src, long 
           if (PRIO == 15) __builtin_amdgcn_s_sleep(0);
           if (PRIO == 16) asm volatile("s_nop 0\n s_branch 1f\n s_nop 0\n1:");
           __builtin_amdgcn_sched_barrier(0);
+          if (PRIO == 18) __builtin_amdgcn_s_setprio(1);
           split8<false>(x, h, m, l, mask_r);
+          __builtin_amdgcn_sched_barrier(0);
+          if (PRIO == 17) __builtin_amdgcn_s_setprio(1);
+          if (PRIO == 18) __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
 #define MFY(a_, b_) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc[1], 0, 0, 0)
           MFY(l, pa); MFY(h, pb); MFY(m, pb); MFY(m, pa); MFY(h, pb); MFY(h, pa);
           __builtin_amdgcn_sched_barrier(0);
+          if (PRIO == 17) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
           for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(x[i]));
         }
@@ -129,6 +143,8 @@ int main() {
   run<44, 6, 1, 14>();
   run<44, 6, 1, 15>();
   run<44, 6, 1, 16>();
+  run<44, 6, 1, 17>();
+  run<44, 6, 1, 18>();
   run<44, 0, 1, 0>();
   run<0, 6, 1, 0>();
   run<44, 6, 1, 0>();
