@@ -381,19 +381,24 @@ def train_leg(dev, world, rank, steps=6, warmup=5, config=2):
         dist.all_gather_object(digests, digest)
     tokens_per_step = world * batch * (t_len - rf)
     flop_step = train_flop_per_step(CFG, batch, t_len, frames)  # per GPU
-    tf = flop_step * steps / dt / 1e12
-    return {"metric": "train-step tokens/sec", "value": tokens_per_step * steps / dt, "unit": "tokens/s",
+    # The leg's figure is the MEDIAN of the timed steps (rank 0's stream events around each step; the ranks run in step
+    # through the all-reduce): one host hiccup -- a 133 ms step among five of 10.1 was seen once in this pool -- would
+    # otherwise triple the mean of six.  The mean over the barrier-bracketed region (max over ranks) and every step's time
+    # are printed beside it.
+    med = sorted(step_ms)[len(step_ms) // 2] * 1e-3
+    return {"metric": "train-step tokens/sec", "value": tokens_per_step / med, "unit": "tokens/s",
             "workload": wl["name"], "conditioned": bool(frames),
-            "ms_per_step": dt / steps * 1e3, "global_batch": world * batch, "seq_len": t_len,
-            # (value and ms_per_step are the MEAN over every timed step; a host hiccup in one step shows here)
-            "step_ms_rank0": [round(x, 3) for x in step_ms], "ms_per_step_median_rank0": sorted(step_ms)[len(step_ms) // 2],
+            "ms_per_step": med * 1e3, "timing": f"median of {steps} timed steps after {warmup} warm-ups",
+            "ms_per_step_mean": dt / steps * 1e3, "tokens_per_s_mean": tokens_per_step * steps / dt,
+            "step_ms_rank0": [round(x, 3) for x in step_ms],
+            "global_batch": world * batch, "seq_len": t_len,
             "tokens_per_step": tokens_per_step, "optimizer": "AdamW (FlatAdamW, one launch)",
             "dtype": "f32 (tensors, accumulation and results; most products formed exactly from three bf16 planes per operand)",
             "loss": float(loss.detach()), "optimizer_launches_per_step": opt.last_launches,
             "param_sha256_per_rank": digests, "allreduce_path": sync.last_path,
             "allreduce_floats": sync.last_floats,
             "flop_per_step_per_gpu": flop_step, "flop_per_token": flop_step / (batch * (t_len - rf)),
-            "roofline": train_roofline(flop_step, train_bytes_per_step(CFG, batch, t_len, frames), dt / steps,
+            "roofline": train_roofline(flop_step, train_bytes_per_step(CFG, batch, t_len, frames), med,
                                        "train_config3" if frames else "train_config2")}
 
 
