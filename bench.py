@@ -784,7 +784,7 @@ def main():
             try:
                 fit = trainer_fit_line(dev)
                 if train and "ms_per_step" in train:
-                    fit["vs_train_step"] = fit["ms_per_step"] / train["ms_per_step"]
+                    fit["vs_train_step"] = fit["ms_per_step"] / train.get("ms_per_step_mean", train["ms_per_step"])  # mean against mean
                 log(f"rank 0: Trainer.fit {fit['ms_per_step']:.2f} ms per step")
             except Exception as e:
                 fit = {"error": f"{type(e).__name__}: {e}"}
