@@ -309,3 +309,18 @@ def test_contiguous_span_rejects_overlap_and_foreign_storage():
     assert contiguous_grad_span([a, b]) is None
     a.grad, b.grad = flat[0:4], torch.zeros(4)       # two storages
     assert contiguous_grad_span([a, b]) is None
+
+
+def test_bench_host_side_arithmetic():
+    """bench.py's host-side pieces that no GPU run exercises here: the byte and FLOP counts of a train step and
+    the CPU baseline of the train step (one step of the oracle at a reduced length; the bench line's sample is B=2, T=16000)."""
+    import bench
+    flop = bench.train_flop_per_step(bench.CFG, 16, 16000)
+    assert abs(flop - 1.1256e12) / 1.1256e12 < 1e-3          # SURVEY 8d: 1.126e12 FLOP per config-2 step
+    nb = bench.train_bytes_per_step(bench.CFG, 16, 16000)
+    assert nb["floor_bytes"] < nb["design_bytes"] < 3 * nb["floor_bytes"]
+    roof = bench.train_roofline(flop, nb, 10e-3, "train_config2")
+    assert roof["bound"] == "hbm" and roof["traffic"] is None and 0 < roof["frac"] < 1 and 0 < roof["mfma"]["frac"] < 1
+    from movenet_amd.utils.weights import make_state_dict
+    r = bench.cpu_train_baseline(make_state_dict(**bench.CFG, seed=0), batch=1, t_len=3072 + 256, n_timed=1, n_warm=0)
+    assert r["unit"] == "tokens/s" and r["kind"] == "port" and r["value"] > 0 and r["cores"] >= 1
