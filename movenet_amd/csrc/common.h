@@ -57,6 +57,32 @@ void parse_switches();
 // ---- device side --------------------------------------------------------
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }
 
+// exp(x) for x <= 0 -- every softmax / cross-entropy kernel's exponential, the maximum already subtracted (r4c): 2^n times
+// v_exp_f32 of the remainder, x log2(e) - n formed with the constant in two pieces, ~2 ulp.  Nine vector instructions where
+// libm's expf compiles to ~25: the two loss kernels issued 3000 - 4100 of them per wave, most of it exponentials.  ONE
+// form for all of them: the fused forward + loss node must return the bits of the plain forward's probabilities.
+__device__ __forceinline__ float sm_exp(float x) {
+  const float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(x, 1.44269502162933349609375f, -n);   // log2(e), high part (24 bits)
+  r = __builtin_fmaf(x, 1.925963033500011e-8f, r);               // ... its remainder
+  const float p = __builtin_amdgcn_exp2f(r);
+  return x < -103.0f ? 0.0f : __builtin_ldexpf(p, (int)n);       // (-inf and anything below the subnormals: exactly 0)
+}
+
+// Column access of the softmax / loss kernels (lane = column, a class row per register): the (Q, S) tensor of ONE sequence
+// as a raw buffer, the lane's column as its per-lane byte offset, the class row as a SCALAR byte offset.  As 64-bit pointers
+// the 64 loads and 64 stores of a thread cost ~380 vector instructions of address arithmetic (v_mad_u64_u32,
+// v_lshl_add_u64) and ~130 registers of addresses (r4c: the loss kernels ran at two waves per SIMD).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t col_rsrc(const float *p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0x7FFFFFFF, 0x00020000);  // raw buffer, 32-bit data format (gfx9)
+}
+__device__ __forceinline__ float col_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void col_st(float x, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+}
+
 // tanh(f) * sigmoid(g), accurate libm forms (parity with the CPU path matters
 // more than the ~100 cycles they cost once per layer).
 __device__ __forceinline__ float gate(float f, float g) {

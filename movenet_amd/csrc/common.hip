@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void ce_probs_fwd_kernel(const float *__restri
       }
     }
     float sum = 0.f;
-    for (int q = 0; q < Q; ++q) sum += expf(col[(size_t)q * S] - m);
+    for (int q = 0; q < Q; ++q) sum += sm_exp(col[(size_t)q * S] - m);
     const long long tg = target[(size_t)b * S + sidx];
     const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
     loss = (m + logf(sum)) - col[(size_t)tq * S];
@@ -231,12 +231,12 @@ __global__ __launch_bounds__(256) void ce_probs_bwd_kernel(const float *__restri
   float m = -INFINITY;
   for (int q = 0; q < Q; ++q) m = fmaxf(m, col[(size_t)q * S]);
   float sum = 0.f;
-  for (int q = 0; q < Q; ++q) sum += expf(col[(size_t)q * S] - m);
+  for (int q = 0; q < Q; ++q) sum += sm_exp(col[(size_t)q * S] - m);
   const float inv = 1.0f / sum;
   const long long tg = target[(size_t)b * S + sidx];
   const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
   for (int q = 0; q < Q; ++q) {
-    const float sm = expf(col[(size_t)q * S] - m) * inv;
+    const float sm = sm_exp(col[(size_t)q * S] - m) * inv;
     dcol[(size_t)q * S] = scale * (sm - (q == tq ? 1.0f : 0.0f));
   }
 }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void ce_probs_cols_kernel(const float *__restr
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < CEQ; ++i) {
-    v[i] = expf(v[i] - m);
+    v[i] = sm_exp(v[i] - m);
     sum += v[i];
   }
   sum = ce_col_reduce(sum, part, wave, lane, false);

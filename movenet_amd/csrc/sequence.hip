@@ -833,11 +833,12 @@ __global__ void softmax_kernel(float *__restrict__ y, int Q, int S) {
   for (int q = 0; q < Q; ++q) m = fmaxf(m, col[(size_t)q * S]);
   float sum = 0.f;
   for (int q = 0; q < Q; ++q) {
-    const float e = expf(col[(size_t)q * S] - m);
+    const float e = sm_exp(col[(size_t)q * S] - m);
     col[(size_t)q * S] = e;
     sum += e;
   }
-  for (int q = 0; q < Q; ++q) col[(size_t)q * S] = col[(size_t)q * S] / sum;
+  const float inv = 1.0f / sum;
+  for (int q = 0; q < Q; ++q) col[(size_t)q * S] = col[(size_t)q * S] * inv;
 }
 
 // dlogit = normalize ? p * (dout - sum_q dout*p) : dout ; zero for columns >= S_out
@@ -875,31 +876,35 @@ __device__ __forceinline__ float col_reduce(float v, float (*part)[64], int wave
 
 __global__ __launch_bounds__(256) void softmax_cols_kernel(float *__restrict__ y, int Q, int S) {
   __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = blockIdx.x * 64 + lane;
   const bool live = s < S;
-  float *col = y + (size_t)b * Q * S + (live ? s : 0);
+  const __amdgpu_buffer_rsrc_t yb = col_rsrc(y + (size_t)b * Q * S);
+  const int voff = 4 * (live ? s : 0), row = 4 * S;
   float v[CQ];
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < CQ; ++i) {
     const int q = CQ * wave + i;
-    v[i] = (live && q < Q) ? col[(size_t)q * S] : -INFINITY;
+    v[i] = q < Q ? col_ld(yb, voff, q * row) : -INFINITY;
+    v[i] = live ? v[i] : -INFINITY;
     m = fmaxf(m, v[i]);
   }
   m = col_reduce(m, part, wave, lane, true);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < CQ; ++i) {
-    v[i] = expf(v[i] - m);  // exp(-inf) = 0 for the padding rows
+    v[i] = sm_exp(v[i] - m);  // exp(-inf) = 0 for the padding rows
     sum += v[i];
   }
   sum = col_reduce(sum, part, wave, lane, false);
   if (!live) return;
+  const float inv = 1.0f / sum;  // (one division per column; softmax_ce_fwd_cols_kernel forms the same bits)
 #pragma unroll
   for (int i = 0; i < CQ; ++i) {
     const int q = CQ * wave + i;
-    if (q < Q) col[(size_t)q * S] = v[i] / sum;
+    if (q < Q) col_st(v[i] * inv, yb, voff, q * row);
   }
 }
 

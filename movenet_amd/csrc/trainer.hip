@@ -13,7 +13,7 @@
 //
 // The arithmetic of the first two is that of softmax_cols_kernel (sequence.hip) followed by
 // ce_probs_cols_kernel (common.hip), operation for operation: the fused forms return the same
-// bits as the two-kernel forms.
+// bits as the two-kernel forms (one exponential for all of them: common.h sm_exp; one division per column).
 #include "common.h"
 
 namespace mvn {
@@ -28,33 +28,39 @@ __device__ __forceinline__ float t_col_reduce(float v, float (*part)[64], int wa
   return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
 }
 
-// 64 columns per workgroup, wave w holds class rows [64w, 64w+64) of them, lane = column
+// 64 columns per workgroup, wave w holds class rows [64w, 64w+64) of them, lane = column (r4c: raw-buffer column accesses and
+// ONE division per column -- common.h col_ld / sm_exp -- 4100 -> ~1900 vector instructions per wave, four waves per SIMD
+// instead of two)
 __global__ __launch_bounds__(256) void softmax_ce_fwd_cols_kernel(float *__restrict__ y,
                                                                   const long long *__restrict__ target,
                                                                   int Q, int S, float *__restrict__ loss_part,
                                                                   int32_t *__restrict__ correct_part) {
   __shared__ float part[4][64];
   __shared__ int argp[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = blockIdx.x * 64 + lane;
   const bool live = s < S;
-  float *col = y + (size_t)b * Q * S + (live ? s : 0);
+  const __amdgpu_buffer_rsrc_t yb = col_rsrc(y + (size_t)b * Q * S);
+  const int voff = 4 * (live ? s : 0), row = 4 * S;
   float v[TQ];
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < TQ; ++i) {
     const int q = TQ * wave + i;
-    v[i] = (live && q < Q) ? col[(size_t)q * S] : -INFINITY;
+    v[i] = q < Q ? col_ld(yb, voff, q * row) : -INFINITY;
+    v[i] = live ? v[i] : -INFINITY;
     m = fmaxf(m, v[i]);
   }
   m = t_col_reduce(m, part, wave, lane, true);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < TQ; ++i) {
-    v[i] = expf(v[i] - m);  // exp(-inf) = 0 for the padding rows
+    v[i] = sm_exp(v[i] - m);  // exp(-inf) = 0 for the padding rows
     sum += v[i];
   }
   sum = t_col_reduce(sum, part, wave, lane, false);
+  const float inv = 1.0f / sum;
   // probabilities (wavenet.py:189-191), then cross_entropy ON them: a second log-softmax
   const long long tg = live ? target[(size_t)b * S + s] : 0;
   const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
@@ -64,8 +70,8 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_cols_kernel(float *__restr
   for (int i = 0; i < TQ; ++i) {
     const int q = TQ * wave + i;
     if (q < Q) {
-      v[i] = v[i] / sum;
-      if (live) col[(size_t)q * S] = v[i];
+      v[i] = v[i] * inv;
+      if (live) col_st(v[i], yb, voff, q * row);
       if (v[i] > m2) {  // strict: first maximum inside this wave's rows
         m2 = v[i];
         arg = q;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_cols_kernel(float *__restr
   m2 = t_col_reduce(m2, part, wave, lane, true);
   float sum2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < TQ; ++i) sum2 += expf(v[i] - m2);
+  for (int i = 0; i < TQ; ++i) sum2 += sm_exp(v[i] - m2);
   sum2 = t_col_reduce(sum2, part, wave, lane, false);
   argp[wave][lane] = wave_m2 == m2 ? arg : 0x7fffffff;
   const float pt_all = t_col_reduce(pt, part, wave, lane, false);  // one wave holds it, the others 0
@@ -101,55 +107,69 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_cols_kernel(float *__restr
   }
 }
 
-// dlogit[b][q][col0 + s] for s < s_cols; zero for s in [S, s_cols)
-__global__ __launch_bounds__(256) void softmax_ce_bwd_cols_kernel(const float *__restrict__ p,
+// (r4c: the column's probabilities are the only array a thread keeps -- the exponentials are formed twice, the second time
+// where the gradient is written, and sum_q dprobs_q p_q comes from two sums of the first pass -- so that four waves fit a
+// SIMD: 248 -> ~110 registers)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void softmax_ce_bwd_cols_kernel(const float *__restrict__ p,
                                                                   const long long *__restrict__ target,
                                                                   int Q, int S, float scale,
                                                                   const float *__restrict__ upstream,
                                                                   float *__restrict__ dlogit, long long d_sb,
                                                                   int d_ld, int col0, int s_cols) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  __shared__ float part[4][64], part2[4][64], part3[4][64];
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = blockIdx.x * 64 + lane;
   const bool live = s < S;
-  const float *col = p + (size_t)b * Q * S + (live ? s : 0);
-  float pv[TQ], e[TQ];
+  const __amdgpu_buffer_rsrc_t pb = col_rsrc(p + (size_t)b * Q * S);
+  const int voff = 4 * (live ? s : 0), row = 4 * S;
+  float pv[TQ];
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < TQ; ++i) {
     const int q = TQ * wave + i;
-    pv[i] = (live && q < Q) ? col[(size_t)q * S] : -INFINITY;
+    pv[i] = q < Q ? col_ld(pb, voff, q * row) : -INFINITY;
+    pv[i] = live ? pv[i] : -INFINITY;
     m = fmaxf(m, pv[i]);
   }
   m = t_col_reduce(m, part, wave, lane, true);
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < TQ; ++i) {
-    e[i] = expf(pv[i] - m);
-    sum += e[i];
-  }
-  sum = t_col_reduce(sum, part, wave, lane, false);
   const long long tg = live ? target[(size_t)b * S + s] : 0;
   const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
+  // one pass: sum_q e_q, sum_q e_q p_q and p_target (e_q = exp(p_q - m); absent rows: e = 0, p taken as 0)
+  float sum = 0.f, s2 = 0.f, pt = 0.f;
+#pragma unroll
+  for (int i = 0; i < TQ; ++i) {
+    const int q = TQ * wave + i;
+    const float e = sm_exp(pv[i] - m);
+    const float pz = (live && q < Q) ? pv[i] : 0.f;
+    sum += e;
+    s2 += e * pz;
+    pt += q == tq ? pz : 0.f;
+  }
+  part[wave][lane] = sum;
+  part2[wave][lane] = s2;
+  part3[wave][lane] = pt;
+  __syncthreads();
+  sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  s2 = (part2[0][lane] + part2[1][lane]) + (part2[2][lane] + part2[3][lane]);
+  pt = (part3[0][lane] + part3[1][lane]) + (part3[2][lane] + part3[3][lane]);
   if (upstream) scale *= *upstream;
   const float inv = 1.0f / sum;
-  // dprobs = scale (softmax(p) - onehot); dlogit = p (dprobs - sum_q dprobs p)
-  float dot = 0.f;
-#pragma unroll
-  for (int i = 0; i < TQ; ++i) {
-    const int q = TQ * wave + i;
-    const bool okq = live && q < Q;
-    e[i] = okq ? scale * (e[i] * inv - (q == tq ? 1.0f : 0.0f)) : 0.f;
-    pv[i] = okq ? pv[i] : 0.f;
-    dot += e[i] * pv[i];
-  }
-  dot = t_col_reduce(dot, part, wave, lane, false);
+  // dprobs_q = scale (softmax(p)_q - onehot_q); dlogit_q = p_q (dprobs_q - sum_k dprobs_k p_k)
+  const float dot = scale * (s2 * inv - pt);
   if (s >= s_cols) return;
-  float *dcol = dlogit + (size_t)b * d_sb + col0 + s;
+  const __amdgpu_buffer_rsrc_t db = col_rsrc(dlogit + (size_t)b * d_sb);
+  const int dvoff = 4 * (col0 + s), drow = 4 * d_ld;
+  float m_again = m;
+  asm volatile("" : "+v"(m_again));  // (or the first pass's 64 exponentials stay in registers for this one)
 #pragma unroll
   for (int i = 0; i < TQ; ++i) {
     const int q = TQ * wave + i;
-    if (q < Q) dcol[(size_t)q * d_ld] = live ? pv[i] * (e[i] - dot) : 0.f;
+    if (q < Q) {
+      const float e = sm_exp(pv[i] - m_again);
+      const float g = scale * (e * inv - (q == tq ? 1.0f : 0.0f));
+      col_st(live ? pv[i] * (g - dot) : 0.f, db, dvoff, q * drow);
+    }
   }
 }
 
@@ -167,14 +187,15 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(float *__restrict__
     for (int q = 0; q < Q; ++q) m = fmaxf(m, col[(size_t)q * S]);
     float sum = 0.f;
     for (int q = 0; q < Q; ++q) {
-      const float ev = expf(col[(size_t)q * S] - m);
+      const float ev = sm_exp(col[(size_t)q * S] - m);
       col[(size_t)q * S] = ev;
       sum += ev;
     }
     float m2 = -INFINITY;
     int arg = 0;
+    const float inv = 1.0f / sum;
     for (int q = 0; q < Q; ++q) {
-      const float pq = col[(size_t)q * S] / sum;
+      const float pq = col[(size_t)q * S] * inv;
       col[(size_t)q * S] = pq;
       if (pq > m2) {
         m2 = pq;
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(float *__restrict__
       }
     }
     float sum2 = 0.f;
-    for (int q = 0; q < Q; ++q) sum2 += expf(col[(size_t)q * S] - m2);
+    for (int q = 0; q < Q; ++q) sum2 += sm_exp(col[(size_t)q * S] - m2);
     const long long tg = target[(size_t)b * S + s];
     const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
     loss = (m2 + logf(sum2)) - col[(size_t)tq * S];
@@ -221,18 +242,18 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float *__rest
   float m = -INFINITY;
   for (int q = 0; q < Q; ++q) m = fmaxf(m, col[(size_t)q * S]);
   float sum = 0.f;
-  for (int q = 0; q < Q; ++q) sum += expf(col[(size_t)q * S] - m);
+  for (int q = 0; q < Q; ++q) sum += sm_exp(col[(size_t)q * S] - m);
   const float inv = 1.0f / sum;
   const long long tg = target[(size_t)b * S + s];
   const int tq = (int)min(max(tg, 0LL), (long long)(Q - 1));
   float dot = 0.f;
   for (int q = 0; q < Q; ++q) {
     const float pq = col[(size_t)q * S];
-    dot += scale * (expf(pq - m) * inv - (q == tq ? 1.0f : 0.0f)) * pq;
+    dot += scale * (sm_exp(pq - m) * inv - (q == tq ? 1.0f : 0.0f)) * pq;
   }
   for (int q = 0; q < Q; ++q) {
     const float pq = col[(size_t)q * S];
-    dcol[(size_t)q * d_ld] = pq * (scale * (expf(pq - m) * inv - (q == tq ? 1.0f : 0.0f)) - dot);
+    dcol[(size_t)q * d_ld] = pq * (scale * (sm_exp(pq - m) * inv - (q == tq ? 1.0f : 0.0f)) - dot);
   }
 }
 
